@@ -1,0 +1,207 @@
+/*
+ * rtk.h -- C ABI of the MI355X (gfx950) ray-trace core.
+ *
+ * The library replaces ONE path of mattkleiny/raytracer-rust: the per-pixel
+ * loop `Camera::render(&self, scene: &Scene) -> Canvas` (src/scene/cameras.rs:72-85)
+ * and everything it calls (`Scene::trace`, src/scene.rs:136-296).  The reference has no
+ * FFI of its own; a Rust host would bind these entry points from an `extern "C"` block
+ * and call `rtk_render` where it calls `camera.render(&scene)` today.
+ *
+ * Conventions
+ *  - Every matrix is 16 doubles, row-major, element (row, column) at [column + 4*row]
+ *    (src/maths/matrices.rs:69-71).
+ *  - Every scene quantity crosses the boundary as f64, exactly as the reference holds
+ *    it.  Narrowing to FP32 happens inside the library, and only where it cannot change
+ *    a decision (see rtk_render).
+ *  - The caller owns every buffer.  The library never frees caller memory and never
+ *    throws or aborts across the boundary; every entry point returns RTK_OK (0) or a
+ *    negative rtk_status and rtk_last_error() describes the failure.
+ *  - A context is used by one thread at a time (the reference renderer is
+ *    single-threaded, src/scene/cameras.rs:75-82); distinct contexts are independent.
+ *  - There is no CPU fallback: without a usable HIP device rtk_create fails.
+ */
+#ifndef RTK_H
+#define RTK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rtk_status {
+  RTK_OK = 0,
+  RTK_ERR_INVALID = -1,         /* NULL pointer, zero size, bad enum value            */
+  RTK_ERR_SINGULAR_CAMERA = -2, /* camera transform has determinant 0; the reference
+                                   panics here (src/scene/cameras.rs:59-62)            */
+  RTK_ERR_UNSUPPORTED = -3,     /* input outside the supported envelope (see below)    */
+  RTK_ERR_HIP = -4,             /* a HIP runtime call failed                           */
+  RTK_ERR_NO_DEVICE = -5,       /* no gfx950 device / library built without a kernel   */
+  RTK_ERR_NOMEM = -6
+} rtk_status;
+
+/* Shape kinds: `PackedKind` (src/loader.rs:52-57). */
+enum { RTK_SPHERE = 0, RTK_PLANE = 1 };
+
+/* Texture kinds: `PackedTexture` (src/loader.rs:137-145) / `Texture` (src/scene/materials.rs:7-10). */
+enum { RTK_TEX_SOLID = 0, RTK_TEX_CHECKER = 1, RTK_TEX_GRADIENT = 2, RTK_TEX_RING = 3, RTK_TEX_STRIPED = 4 };
+
+/* Recursion limit of the reference: `Scene::MAX_DEPTH` (src/scene.rs:109). */
+#define RTK_REFERENCE_MAX_DEPTH 5
+/* Largest max_depth the device path accepts (bounds the per-pixel ray stack). */
+#define RTK_MAX_DEPTH_LIMIT 8
+/* Frame tile used for the multi-GPU partition: RTK_TILE_W x RTK_TILE_H pixels. */
+#define RTK_TILE_W 32
+#define RTK_TILE_H 8
+
+/* `Material` (src/scene/materials.rs:23-32).  For RTK_TEX_SOLID only color_a is used. */
+typedef struct rtk_material {
+  uint32_t texture_kind;
+  uint32_t reserved_;
+  double color_a[3];
+  double color_b[3];
+  double ambient, diffuse, specular, shininess;
+  double transparency, reflectivity, refractivity;
+} rtk_material;
+
+/* `SceneNode<S>` (src/scene.rs:36-41).  The inverse transform is derived inside the
+ * library with the reference's cofactor method (src/maths/matrices.rs:183-198); a
+ * singular transform silently gets an identity inverse (src/scene.rs:55-62). */
+typedef struct rtk_object {
+  uint32_t kind; /* RTK_SPHERE | RTK_PLANE */
+  uint32_t reserved_;
+  double transform[16];
+  double plane_normal[4]; /* `Plane::normal` (src/scene/shapes/planes.rs:10-12); ignored for spheres */
+  rtk_material material;
+} rtk_object;
+
+/* `PointLight` (src/scene/lighting.rs:8-11).  position[3] is the reference's `w`: lights
+ * loaded from YAML are built with `vec3` and carry w = 0 (src/loader.rs:35-40), lights
+ * built with `point()` carry w = 1.  The value changes shadow rays and Phong shading,
+ * so it is part of the interface. */
+typedef struct rtk_light {
+  double position[4];
+  double intensity[3];
+} rtk_light;
+
+/* `Scene` (src/scene.rs:102-106). */
+typedef struct rtk_scene {
+  const rtk_object* objects;
+  uint32_t n_objects;
+  const rtk_light* lights;
+  uint32_t n_lights;
+  double ambient_color[3]; /* `Scene::ambient_color`; the reference only ever holds BLACK outside tests */
+  uint32_t max_depth;      /* RTK_REFERENCE_MAX_DEPTH reproduces the reference */
+  uint32_t reserved_;
+} rtk_scene;
+
+/* `Camera` (src/scene/cameras.rs:7-15). */
+typedef struct rtk_camera {
+  uint32_t width, height;
+  double half_width, half_height;
+  double field_of_view;
+  double pixel_size;
+  double transform[16];
+} rtk_camera;
+
+/* Ray counts use the reference's unit: one ray = one call of `Scene::intersect`
+ * (src/scene.rs:146 for primary and secondary rays, src/scene.rs:217 for shadow rays). */
+typedef struct rtk_stats {
+  uint64_t rays_primary;
+  uint64_t rays_shadow;
+  uint64_t rays_secondary;
+  uint64_t exact_tests; /* (ray, object) pairs that needed the f64 re-evaluation */
+  double kernel_ms;     /* HIP-event time of the trace kernel(s) of the last call */
+} rtk_stats;
+
+/* Which tiles of the frame a call renders.  Tiles are RTK_TILE_W x RTK_TILE_H pixels,
+ * numbered row-major over ceil(width/RTK_TILE_W) x ceil(height/RTK_TILE_H).  A call
+ * renders the tiles t with t % world == rank.  world == 1 renders the whole frame
+ * straight into row-major images.  With world > 1 the output is compact:
+ * local tile k (global tile k*world + rank) occupies pixels
+ * [k*RTK_TILE_W*RTK_TILE_H, (k+1)*RTK_TILE_W*RTK_TILE_H) in row-major order inside the
+ * tile; rtk_untile() rebuilds the frame from the gathered buffers. */
+typedef struct rtk_tiling {
+  uint32_t rank;
+  uint32_t world;
+} rtk_tiling;
+
+typedef struct rtk_context rtk_context;           /* opaque: one HIP device, stream, scratch */
+typedef struct rtk_scene_handle rtk_scene_handle; /* opaque: a scene resident in HBM        */
+
+/* `Camera::new` (src/scene/cameras.rs:19-49): derives half_width, half_height and
+ * pixel_size from (width, height, field_of_view) and sets the default view
+ * look_at((0,1.5,-5), (0,1,0), (0,1,0)). */
+int rtk_camera_init(rtk_camera* camera, uint32_t width, uint32_t height, double field_of_view);
+
+/* Number of tiles a rank owns, and the number of pixels of its compact buffer. */
+uint64_t rtk_tiles_for_rank(uint32_t width, uint32_t height, uint32_t rank, uint32_t world);
+uint64_t rtk_compact_pixels(uint32_t width, uint32_t height, uint32_t rank, uint32_t world);
+
+/* Binds a context to HIP device `device_id`.  Fails with RTK_ERR_NO_DEVICE when the
+ * device is absent or is not gfx950. */
+int rtk_create(int device_id, rtk_context** out);
+void rtk_destroy(rtk_context* ctx);
+
+/* Flattens a scene for the device and copies it to HBM: the counterpart of building a
+ * `Scene` with `add_object` / `add_light` (src/scene.rs:120-133) and of
+ * `SceneNode::with_transform` pre-computing the inverse (src/scene.rs:55-62).
+ * Supported envelope (anything else returns RTK_ERR_UNSUPPORTED):
+ *  - object and camera transforms are affine (last row 0 0 0 1), as every constructor
+ *    in src/maths/transforms.rs produces;
+ *  - plane_normal[3] == 0 (the loader always passes vec3(0,1,0), src/loader.rs:90);
+ *  - max_depth <= RTK_MAX_DEPTH_LIMIT, n_lights <= 64. */
+int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle** out);
+void rtk_scene_release(rtk_context* ctx, rtk_scene_handle* scene);
+
+/* `Camera::render` (src/scene/cameras.rs:72-85) on the device, outputs in DEVICE memory.
+ *  d_rgb_f32 : W*H*3 floats, pixel (x, y) at 3*(x + y*W)  -- `Canvas::pixels` layout
+ *              (src/graphics.rs:40-46) narrowed to FP32; may be NULL.
+ *  d_rgba8   : W*H*4 bytes, `(c * 255.0) as u8` per channel, alpha 255 -- the cast of
+ *              `Canvas::to_image` (src/graphics.rs:59-74): truncation toward zero,
+ *              saturation at 0 and 255, NaN -> 0; may be NULL.
+ *  tiling    : NULL means {0, 1}.  With world > 1 both outputs use the compact layout
+ *              described at rtk_tiling and hold rtk_compact_pixels() pixels.
+ *  hip_stream: a hipStream_t, or NULL for the context's own stream.  The call is
+ *              asynchronous on that stream.
+ * Precision: object sweeps run a conservative FP32 filter; every candidate the filter
+ * keeps, and all shading, is evaluated in f64 with the reference's formulas, so the
+ * colour differs from an f64 render only by FMA contraction and summation order before
+ * the final narrowing to FP32. */
+int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera,
+                      const rtk_tiling* tiling, float* d_rgb_f32, uint8_t* d_rgba8,
+                      void* hip_stream);
+
+/* Same render with HOST output buffers (whole frame, row-major); uploads the scene,
+ * renders, copies back and synchronises.  stats may be NULL. */
+int rtk_render(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camera,
+               float* rgb_f32_out, uint8_t* rgba8_out, rtk_stats* stats);
+
+/* `Scene::trace(&self, ray: Ray) -> Color` (src/scene.rs:136-138) for n caller-supplied
+ * rays: origins and directions are n x 4 doubles (x, y, z, w), colors_out n x 3 doubles.
+ * All three are HOST pointers; the call synchronises.  Origins must have w = 1 and
+ * directions w = 0 (what `Camera::ray_for_pixel` produces). */
+int rtk_trace_rays(rtk_context* ctx, rtk_scene_handle* scene, const double* origins,
+                   const double* directions, uint64_t n, double* colors_out);
+
+/* Rebuilds row-major frames from `world` compact buffers laid end to end in rank order
+ * (what a gather to rank 0 produces).  Each rank's slot is `slot_pixels` pixels long
+ * (>= rtk_compact_pixels of every rank).  Device pointers; either pair may be NULL. */
+int rtk_untile(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t world,
+               uint64_t slot_pixels, const float* d_rgb_f32_compact, float* d_rgb_f32_frame,
+               const uint8_t* d_rgba8_compact, uint8_t* d_rgba8_frame, void* hip_stream);
+
+/* Waits for the stream of the last render and returns its ray counts and kernel time. */
+int rtk_get_stats(rtk_context* ctx, rtk_stats* stats);
+
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char* rtk_last_error(void);
+
+/* Library version string and the code-object architecture it was built for. */
+const char* rtk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTK_H */

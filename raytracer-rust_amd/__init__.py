@@ -15,3 +15,4 @@ from .host import (  # noqa: F401
     BLACK, WHITE, RED,
 )
 from .loader import PackedScene  # noqa: F401
+from .canvas import Canvas  # noqa: F401

@@ -1,0 +1,562 @@
+// rtk_api.hip -- the C ABI of include/rtk.h: validation, scene flattening, HBM residency
+// and kernel launches.  Host code only; the kernels live in rtk_kernels.hip.
+//
+// There is no CPU rendering path in this library: every entry point that produces pixels
+// launches the gfx950 kernels and fails with an error code when no device is usable.
+
+#include "../../include/rtk.h"
+#include "rtk_device.h"
+#include "rtk_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+  g_error = msg;
+  return code;
+}
+int fail_hip(hipError_t e, const char* what) {
+  g_error = std::string(what) + ": " + hipGetErrorString(e);
+  return RTK_ERR_HIP;
+}
+#define RTK_HIP(call)                                   \
+  do {                                                  \
+    hipError_t e_ = (call);                             \
+    if (e_ != hipSuccess) return fail_hip(e_, #call);   \
+  } while (0)
+
+// ---------------------------------------------------------------- f64 matrix helpers
+// Row-major 4x4, element (row, col) at [col + 4*row] (src/maths/matrices.rs:69-71).
+struct M4 {
+  double e[16];
+  double at(int r, int c) const { return e[c + 4 * r]; }
+  double& at(int r, int c) { return e[c + 4 * r]; }
+};
+M4 m4_identity() {
+  M4 m{};
+  for (int i = 0; i < 4; ++i) m.at(i, i) = 1.0;
+  return m;
+}
+M4 m4_load(const double* p) {
+  M4 m;
+  std::memcpy(m.e, p, sizeof m.e);
+  return m;
+}
+// Laplace expansion along the first row of an n x n block held with row stride n, the way
+// the reference computes determinants (src/maths/matrices.rs:172-180, 256-264, 282-286).
+double det_n(const double* m, int n) {
+  if (n == 2) return m[0] * m[3] - m[1] * m[2];
+  double result = 0.0;
+  double sub[9];
+  for (int i = 0; i < n; ++i) {
+    int k = 0;
+    for (int y = 1; y < n; ++y)
+      for (int x = 0; x < n; ++x)
+        if (x != i) sub[k++] = m[x + y * n];
+    double minor = det_n(sub, n - 1);
+    result += m[i] * ((i % 2 == 0) ? minor : -minor);
+  }
+  return result;
+}
+double cofactor4(const M4& m, int row, int col) {
+  double sub[9];
+  int k = 0;
+  for (int y = 0; y < 4; ++y)
+    for (int x = 0; x < 4; ++x)
+      if (y != row && x != col) sub[k++] = m.at(y, x);
+  double minor = det_n(sub, 3);
+  return ((row + col) % 2 == 0) ? minor : -minor;
+}
+// Inverse by cofactors / determinant (src/maths/matrices.rs:183-198).  false = singular.
+bool m4_invert(const M4& m, M4& out) {
+  double det = det_n(m.e, 4);
+  if (det == 0.0) return false;
+  for (int row = 0; row < 4; ++row)
+    for (int col = 0; col < 4; ++col) out.at(col, row) = cofactor4(m, row, col) / det;
+  return true;
+}
+bool is_affine(const double* t) { return t[12] == 0.0 && t[13] == 0.0 && t[14] == 0.0 && t[15] == 1.0; }
+
+// Largest singular value of the upper-left 3x3 (the radius of the smallest origin-centred
+// ball containing the image of the unit sphere), never under-estimated.
+double sigma_max3(const M4& t) {
+  double a[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      a[i][j] = 0.0;
+      for (int k = 0; k < 3; ++k) a[i][j] += t.at(k, i) * t.at(k, j);  // M^T M
+    }
+  const double tr = a[0][0] + a[1][1] + a[2][2];
+  const double off = std::fabs(a[0][1]) + std::fabs(a[0][2]) + std::fabs(a[1][2]);
+  const double dmax = std::fmax(a[0][0], std::fmax(a[1][1], a[2][2]));
+  if (off <= 1e-14 * tr) return std::sqrt(dmax) * (1.0 + 1e-12);  // rotation * axis scaling up to round-off
+  // cyclic Jacobi on the symmetric 3x3
+  for (int sweep = 0; sweep < 32; ++sweep) {
+    double o = std::fabs(a[0][1]) + std::fabs(a[0][2]) + std::fabs(a[1][2]);
+    if (o <= 1e-18 * tr) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (a[p][q] == 0.0) continue;
+        double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        double tt = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        double c = 1.0 / std::sqrt(tt * tt + 1.0), s = tt * c;
+        for (int k = 0; k < 3; ++k) {
+          double akp = a[k][p], akq = a[k][q];
+          a[k][p] = c * akp - s * akq;
+          a[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double apk = a[p][k], aqk = a[q][k];
+          a[p][k] = c * apk - s * aqk;
+          a[q][k] = s * apk + c * aqk;
+        }
+      }
+  }
+  double lam = std::fmax(a[0][0], std::fmax(a[1][1], a[2][2]));
+  double o = std::fabs(a[0][1]) + std::fabs(a[0][2]) + std::fabs(a[1][2]);
+  return std::sqrt(lam + o) * (1.0 + 1e-9);  // Gershgorin: leftover off-diagonal mass only enlarges
+}
+
+float round_up(double v) {
+  float f = (float)v;
+  if ((double)f < v) f = std::nextafterf(f, INFINITY);
+  return f;
+}
+
+uint32_t round_up_to(uint32_t n, uint32_t m) { return (n + m - 1) / m * m; }
+
+}  // namespace
+
+// ---------------------------------------------------------------- opaque handles
+struct rtk_scene_handle {
+  rtk::DevScene dev{};
+  void* d_objects = nullptr;
+  void* d_lights = nullptr;
+  void* d_filter = nullptr;
+  void* d_exact = nullptr;
+  void* d_sph_object = nullptr;
+  void* d_plane_object = nullptr;
+  float4* d_prim = nullptr;  // primary-ray filter records (rebuilt per camera)
+};
+
+struct rtk_context {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  rtk::DevCounters* d_counters = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool have_timing = false;
+  // staging for rtk_render (host-buffer variant)
+  float* d_rgb = nullptr;
+  uint8_t* d_rgba8 = nullptr;
+  size_t cap_pixels = 0;
+};
+
+extern "C" {
+
+const char* rtk_last_error(void) { return g_error.c_str(); }
+
+const char* rtk_version(void) { return "rtk 0.1 (gfx950, HIP)"; }
+
+int rtk_camera_init(rtk_camera* camera, uint32_t width, uint32_t height, double fov) {
+  if (!camera || width == 0 || height == 0) return fail(RTK_ERR_INVALID, "rtk_camera_init: null camera or zero size");
+  // src/scene/cameras.rs:19-49
+  const double half_view = std::tan(fov / 2.0);
+  const double aspect = (double)width / (double)height;
+  double half_width, half_height;
+  if (aspect >= 1.0) {
+    half_width = half_view;
+    half_height = half_width / aspect;
+  } else {
+    half_width = half_view * aspect;
+    half_height = half_view;
+  }
+  camera->width = width;
+  camera->height = height;
+  camera->half_width = half_width;
+  camera->half_height = half_height;
+  camera->field_of_view = fov;
+  camera->pixel_size = (half_width * 2.0) / (double)width;
+  // look_at(point(0,1.5,-5), point(0,1,0), vec3(0,1,0)) (src/maths/transforms.rs:67-80)
+  const double from[3] = {0.0, 1.5, -5.0}, to[3] = {0.0, 1.0, 0.0}, up[3] = {0.0, 1.0, 0.0};
+  double f[3] = {to[0] - from[0], to[1] - from[1], to[2] - from[2]};
+  double fm = std::sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2] + 0.0 * 0.0);
+  for (double& v : f) v /= fm;
+  double um = std::sqrt(up[0] * up[0] + up[1] * up[1] + up[2] * up[2] + 0.0 * 0.0);
+  double u[3] = {up[0] / um, up[1] / um, up[2] / um};
+  double left[3] = {f[1] * u[2] - f[2] * u[1], f[2] * u[0] - f[0] * u[2], f[0] * u[1] - f[1] * u[0]};
+  double tu[3] = {left[1] * f[2] - left[2] * f[1], left[2] * f[0] - left[0] * f[2], left[0] * f[1] - left[1] * f[0]};
+  M4 orientation = m4_identity();
+  for (int c = 0; c < 3; ++c) {
+    orientation.at(0, c) = left[c];
+    orientation.at(1, c) = tu[c];
+    orientation.at(2, c) = -f[c];
+  }
+  M4 tr = m4_identity();
+  tr.at(0, 3) = -from[0];
+  tr.at(1, 3) = -from[1];
+  tr.at(2, 3) = -from[2];
+  M4 out{};
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double sum = 0.0;
+      for (int i = 0; i < 4; ++i) sum += orientation.at(r, i) * tr.at(i, c);
+      out.at(r, c) = sum;
+    }
+  std::memcpy(camera->transform, out.e, sizeof out.e);
+  return RTK_OK;
+}
+
+uint64_t rtk_tiles_for_rank(uint32_t width, uint32_t height, uint32_t rank, uint32_t world) {
+  if (world == 0 || rank >= world) return 0;
+  const uint64_t tiles = (uint64_t)((width + RTK_TILE_W - 1) / RTK_TILE_W) * ((height + RTK_TILE_H - 1) / RTK_TILE_H);
+  return tiles / world + ((tiles % world) > rank ? 1 : 0);
+}
+
+uint64_t rtk_compact_pixels(uint32_t width, uint32_t height, uint32_t rank, uint32_t world) {
+  return rtk_tiles_for_rank(width, height, rank, world) * (uint64_t)(RTK_TILE_W * RTK_TILE_H);
+}
+
+int rtk_create(int device_id, rtk_context** out) {
+  if (!out) return fail(RTK_ERR_INVALID, "rtk_create: null out pointer");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) return fail(RTK_ERR_NO_DEVICE, "rtk_create: no HIP device available");
+  if (device_id < 0 || device_id >= count) return fail(RTK_ERR_NO_DEVICE, "rtk_create: device id out of range");
+  hipDeviceProp_t prop;
+  RTK_HIP(hipGetDeviceProperties(&prop, device_id));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(RTK_ERR_NO_DEVICE, std::string("rtk_create: kernels are built for gfx950, device is ") + prop.gcnArchName);
+  RTK_HIP(hipSetDevice(device_id));
+  rtk_context* ctx = new (std::nothrow) rtk_context();
+  if (!ctx) return fail(RTK_ERR_NOMEM, "rtk_create: out of host memory");
+  ctx->device = device_id;
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&ctx->ev_start)) != hipSuccess || (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
+      (e = hipMalloc((void**)&ctx->d_counters, sizeof(rtk::DevCounters))) != hipSuccess ||
+      (e = hipMemset(ctx->d_counters, 0, sizeof(rtk::DevCounters))) != hipSuccess) {
+    rtk_destroy(ctx);
+    return fail_hip(e, "rtk_create");
+  }
+  *out = ctx;
+  return RTK_OK;
+}
+
+void rtk_destroy(rtk_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
+  if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
+  if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+void rtk_scene_release(rtk_context* ctx, rtk_scene_handle* h) {
+  if (!h) return;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  void* ptrs[] = {h->d_objects, h->d_lights, h->d_filter, h->d_exact, h->d_sph_object, h->d_plane_object, h->d_prim};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete h;
+}
+
+int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle** out) {
+  if (!ctx || !scene || !out) return fail(RTK_ERR_INVALID, "rtk_scene_upload: null argument");
+  *out = nullptr;
+  if ((scene->n_objects && !scene->objects) || (scene->n_lights && !scene->lights))
+    return fail(RTK_ERR_INVALID, "rtk_scene_upload: null object or light array");
+  if (scene->max_depth > RTK_MAX_DEPTH_LIMIT) return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: max_depth above RTK_MAX_DEPTH_LIMIT");
+  if (scene->n_lights > 64) return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: more than 64 lights");
+
+  using namespace rtk;
+  std::vector<DevObject> objects(scene->n_objects);
+  std::vector<DevLight> lights(scene->n_lights);
+  std::vector<uint32_t> sph_object, plane_object;
+  std::vector<double4> sph_exact;
+  bool track_n1 = false, any_secondary = false;
+
+  for (uint32_t i = 0; i < scene->n_objects; ++i) {
+    const rtk_object& src = scene->objects[i];
+    if (src.kind != RTK_SPHERE && src.kind != RTK_PLANE) return fail(RTK_ERR_INVALID, "rtk_scene_upload: unknown object kind");
+    if (src.material.texture_kind > RTK_TEX_STRIPED) return fail(RTK_ERR_INVALID, "rtk_scene_upload: unknown texture kind");
+    if (!is_affine(src.transform))
+      return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: object transform is not affine (last row must be 0 0 0 1)");
+    if (src.kind == RTK_PLANE && src.plane_normal[3] != 0.0)
+      return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: plane_normal[3] must be 0");
+    M4 t = m4_load(src.transform), inv;
+    bool invertible = m4_invert(t, inv);
+    if (!invertible) {  // src/scene.rs:55-62: identity inverse
+      inv = m4_identity();
+      t = m4_identity();
+    }
+    DevObject& o = objects[i];
+    std::memcpy(o.inv, inv.e, sizeof o.inv);
+    std::memcpy(o.color_a, src.material.color_a, sizeof o.color_a);
+    std::memcpy(o.color_b, src.material.color_b, sizeof o.color_b);
+    o.ambient = src.material.ambient;
+    o.diffuse = src.material.diffuse;
+    o.specular = src.material.specular;
+    o.shininess = src.material.shininess;
+    o.transparency = src.material.transparency;
+    o.reflectivity = src.material.reflectivity;
+    o.refractivity = src.material.refractivity;
+    std::memcpy(o.plane_normal, src.plane_normal, sizeof o.plane_normal);
+    o.kind = src.kind;
+    o.texture_kind = src.material.texture_kind;
+    if (o.refractivity != 1.0) track_n1 = true;
+    if (!(std::fabs(o.reflectivity) < 0.00001) || !(std::fabs(o.transparency) < 0.00001)) any_secondary = true;
+    if (src.kind == RTK_PLANE) {
+      plane_object.push_back(i);
+    } else {
+      // bounding ball of the transformed unit sphere: centre = translation, radius = sigma_max
+      sph_object.push_back(i);
+      sph_exact.push_back(make_double4(t.at(0, 3), t.at(1, 3), t.at(2, 3), sigma_max3(t)));
+    }
+  }
+  for (uint32_t k = 0; k < scene->n_lights; ++k) {
+    std::memcpy(lights[k].pos, scene->lights[k].position, sizeof lights[k].pos);
+    std::memcpy(lights[k].intensity, scene->lights[k].intensity, sizeof lights[k].intensity);
+    lights[k].reserved_ = 0.0;
+  }
+
+  // FP32 filter records, recentred on the middle of the sphere centres' bounding box
+  const uint32_t n_sph = (uint32_t)sph_exact.size();
+  const uint32_t n_pad = round_up_to(n_sph, kGroup);
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  for (uint32_t i = 0; i < n_sph; ++i) {
+    const double c[3] = {sph_exact[i].x, sph_exact[i].y, sph_exact[i].z};
+    for (int a = 0; a < 3; ++a) {
+      if (i == 0 || c[a] < lo[a]) lo[a] = c[a];
+      if (i == 0 || c[a] > hi[a]) hi[a] = c[a];
+    }
+  }
+  double center[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+  std::vector<float4> filter(n_pad);
+  float r2_max = 0.f, r_max = 0.f, c_max = 0.f;
+  for (uint32_t i = 0; i < n_pad; ++i) {
+    if (i >= n_sph) {
+      filter[i] = make_float4(0.f, 0.f, 0.f, -1.0e30f);  // h^2 - (k|u|^2 + 1e30) never reaches the threshold
+      continue;
+    }
+    const double c[3] = {sph_exact[i].x - center[0], sph_exact[i].y - center[1], sph_exact[i].z - center[2]};
+    const float cf[3] = {(float)c[0], (float)c[1], (float)c[2]};
+    const double dx = c[0] - cf[0], dy = c[1] - cf[1], dz = c[2] - cf[2];
+    const double shift = std::sqrt(dx * dx + dy * dy + dz * dz);  // actual displacement of the rounded centre
+    const double R = sph_exact[i].w * (1.0 + 1e-9) + shift * 1.0001;
+    const float r2 = round_up(R * R);
+    filter[i] = make_float4(cf[0], cf[1], cf[2], r2);
+    r2_max = std::fmax(r2_max, r2);
+    r_max = std::fmax(r_max, round_up(R));
+    c_max = std::fmax(c_max, round_up(std::sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]) * 1.0001));
+  }
+
+  rtk_scene_handle* h = new (std::nothrow) rtk_scene_handle();
+  if (!h) return fail(RTK_ERR_NOMEM, "rtk_scene_upload: out of host memory");
+  hipError_t e = hipSetDevice(ctx->device);
+  auto upload = [&](void** dst, const void* src, size_t bytes) {
+    if (e != hipSuccess || bytes == 0) return;
+    e = hipMalloc(dst, bytes);
+    if (e == hipSuccess) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  upload(&h->d_objects, objects.data(), objects.size() * sizeof(DevObject));
+  upload(&h->d_lights, lights.data(), lights.size() * sizeof(DevLight));
+  upload(&h->d_filter, filter.data(), filter.size() * sizeof(float4));
+  upload(&h->d_exact, sph_exact.data(), sph_exact.size() * sizeof(double4));
+  upload(&h->d_sph_object, sph_object.data(), sph_object.size() * sizeof(uint32_t));
+  upload(&h->d_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
+  if (e == hipSuccess && n_pad) e = hipMalloc((void**)&h->d_prim, n_pad * sizeof(float4));
+  if (e != hipSuccess) {
+    rtk_scene_release(ctx, h);
+    return fail_hip(e, "rtk_scene_upload");
+  }
+  DevScene& d = h->dev;
+  d.objects = (const DevObject*)h->d_objects;
+  d.lights = (const DevLight*)h->d_lights;
+  d.sph_filter = (const float4*)h->d_filter;
+  d.sph_exact = (const double4*)h->d_exact;
+  d.sph_object = (const uint32_t*)h->d_sph_object;
+  d.plane_object = (const uint32_t*)h->d_plane_object;
+  d.n_objects = scene->n_objects;
+  d.n_lights = scene->n_lights;
+  d.n_spheres = n_sph;
+  d.n_spheres_padded = n_pad;
+  d.n_planes = (uint32_t)plane_object.size();
+  d.max_depth = scene->max_depth;
+  d.track_n1 = track_n1 ? 1u : 0u;
+  d.any_secondary = any_secondary ? 1u : 0u;
+  std::memcpy(d.center, center, sizeof center);
+  std::memcpy(d.ambient, scene->ambient_color, sizeof d.ambient);
+  d.r2_max = r2_max;
+  d.r_max = r_max;
+  d.c_max = c_max;
+  d.pad_ = 0.f;
+  *out = h;
+  return RTK_OK;
+}
+
+static int make_dev_camera(const rtk_camera* camera, rtk::DevCamera& c) {
+  if (camera->width == 0 || camera->height == 0) return fail(RTK_ERR_INVALID, "camera has zero size");
+  if (!is_affine(camera->transform))
+    return fail(RTK_ERR_UNSUPPORTED, "camera transform is not affine (last row must be 0 0 0 1)");
+  M4 inv;
+  if (!m4_invert(m4_load(camera->transform), inv))
+    return fail(RTK_ERR_SINGULAR_CAMERA, "Failed to invert camera transform");  // src/scene/cameras.rs:59-62
+  c.width = camera->width;
+  c.height = camera->height;
+  c.half_width = camera->half_width;
+  c.half_height = camera->half_height;
+  c.pixel_size = camera->pixel_size;
+  std::memcpy(c.inv, inv.e, sizeof c.inv);
+  // inverse * point(0, 0, 0): the 4-term row sums collapse to the last column
+  for (int r = 0; r < 3; ++r) c.origin[r] = inv.at(r, 0) * 0.0 + inv.at(r, 1) * 0.0 + inv.at(r, 2) * 0.0 + inv.at(r, 3) * 1.0;
+  return RTK_OK;
+}
+
+int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, const rtk_tiling* tiling,
+                      float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream) {
+  if (!ctx || !scene || !camera) return fail(RTK_ERR_INVALID, "rtk_render_device: null argument");
+  rtk::DevCamera cam;
+  int rc = make_dev_camera(camera, cam);
+  if (rc != RTK_OK) return rc;
+  rtk_tiling tl = {0u, 1u};
+  if (tiling) tl = *tiling;
+  if (tl.world == 0 || tl.rank >= tl.world) return fail(RTK_ERR_INVALID, "rtk_render_device: bad tiling (rank >= world)");
+  rtk::RenderTarget t{};
+  t.rgb = d_rgb_f32;
+  t.rgba8 = d_rgba8;
+  t.tiles_x = (camera->width + RTK_TILE_W - 1) / RTK_TILE_W;
+  t.tiles_y = (camera->height + RTK_TILE_H - 1) / RTK_TILE_H;
+  t.rank = tl.rank;
+  t.world = tl.world;
+  const uint64_t n_local = rtk_tiles_for_rank(camera->width, camera->height, tl.rank, tl.world);
+  if (n_local > 0x7fffffffull) return fail(RTK_ERR_UNSUPPORTED, "rtk_render_device: frame has too many tiles");
+  t.n_local_tiles = (uint32_t)n_local;
+  t.compact = tl.world > 1 ? 1u : 0u;
+
+  RTK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  RTK_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters), st));
+  RTK_HIP(rtk::launch_prep_primary(st, scene->dev, cam, scene->d_prim));
+  RTK_HIP(hipEventRecord(ctx->ev_start, st));
+  RTK_HIP(rtk::launch_render(st, scene->dev, cam, scene->d_prim, t, ctx->d_counters));
+  RTK_HIP(hipEventRecord(ctx->ev_stop, st));
+  ctx->last_stream = st;
+  ctx->have_timing = true;
+  return RTK_OK;
+}
+
+int rtk_get_stats(rtk_context* ctx, rtk_stats* stats) {
+  if (!ctx || !stats) return fail(RTK_ERR_INVALID, "rtk_get_stats: null argument");
+  std::memset(stats, 0, sizeof *stats);
+  if (!ctx->have_timing) return RTK_OK;
+  RTK_HIP(hipSetDevice(ctx->device));
+  RTK_HIP(hipEventSynchronize(ctx->ev_stop));
+  float ms = 0.f;
+  RTK_HIP(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+  rtk::DevCounters c;
+  RTK_HIP(hipMemcpyAsync(&c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost, ctx->last_stream));
+  RTK_HIP(hipStreamSynchronize(ctx->last_stream));
+  stats->rays_primary = c.rays_primary;
+  stats->rays_shadow = c.rays_shadow;
+  stats->rays_secondary = c.rays_secondary;
+  stats->exact_tests = c.exact_tests;
+  stats->kernel_ms = ms;
+  return RTK_OK;
+}
+
+int rtk_render(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camera, float* rgb_f32_out, uint8_t* rgba8_out,
+               rtk_stats* stats) {
+  if (!ctx || !scene || !camera) return fail(RTK_ERR_INVALID, "rtk_render: null argument");
+  rtk_scene_handle* h = nullptr;
+  int rc = rtk_scene_upload(ctx, scene, &h);
+  if (rc != RTK_OK) return rc;
+  const size_t pixels = (size_t)camera->width * camera->height;
+  if (pixels > ctx->cap_pixels) {
+    if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
+    if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
+    ctx->d_rgb = nullptr;
+    ctx->d_rgba8 = nullptr;
+    ctx->cap_pixels = 0;
+    hipError_t e = hipMalloc((void**)&ctx->d_rgb, pixels * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_rgba8, pixels * 4);
+    if (e != hipSuccess) {
+      rtk_scene_release(ctx, h);
+      return fail_hip(e, "rtk_render: framebuffer allocation");
+    }
+    ctx->cap_pixels = pixels;
+  }
+  rc = rtk_render_device(ctx, h, camera, nullptr, rgb_f32_out ? ctx->d_rgb : nullptr, rgba8_out ? ctx->d_rgba8 : nullptr,
+                         nullptr);
+  hipError_t e = hipSuccess;
+  if (rc == RTK_OK && rgb_f32_out)
+    e = hipMemcpyAsync(rgb_f32_out, ctx->d_rgb, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (rc == RTK_OK && e == hipSuccess && rgba8_out)
+    e = hipMemcpyAsync(rgba8_out, ctx->d_rgba8, pixels * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (rc == RTK_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (rc == RTK_OK && e != hipSuccess) rc = fail_hip(e, "rtk_render: copy back");
+  if (rc == RTK_OK && stats) rc = rtk_get_stats(ctx, stats);
+  rtk_scene_release(ctx, h);
+  return rc;
+}
+
+int rtk_trace_rays(rtk_context* ctx, rtk_scene_handle* scene, const double* origins, const double* directions, uint64_t n,
+                   double* colors_out) {
+  if (!ctx || !scene || (n && (!origins || !directions || !colors_out)))
+    return fail(RTK_ERR_INVALID, "rtk_trace_rays: null argument");
+  for (uint64_t i = 0; i < n; ++i)
+    if (origins[4 * i + 3] != 1.0 || directions[4 * i + 3] != 0.0)
+      return fail(RTK_ERR_UNSUPPORTED, "rtk_trace_rays: origins need w = 1 and directions w = 0");
+  if (n == 0) return RTK_OK;
+  RTK_HIP(hipSetDevice(ctx->device));
+  double *d_o = nullptr, *d_d = nullptr, *d_c = nullptr;
+  hipError_t e = hipMalloc((void**)&d_o, n * 4 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_d, n * 4 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_c, n * 3 * sizeof(double));
+  hipStream_t st = ctx->stream;
+  if (e == hipSuccess) e = hipMemcpyAsync(d_o, origins, n * 4 * sizeof(double), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_d, directions, n * 4 * sizeof(double), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters), st);
+  if (e == hipSuccess) e = hipEventRecord(ctx->ev_start, st);
+  if (e == hipSuccess) e = rtk::launch_trace_rays(st, scene->dev, d_o, d_d, n, d_c, ctx->d_counters);
+  if (e == hipSuccess) e = hipEventRecord(ctx->ev_stop, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(colors_out, d_c, n * 3 * sizeof(double), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (d_o) (void)hipFree(d_o);
+  if (d_d) (void)hipFree(d_d);
+  if (d_c) (void)hipFree(d_c);
+  if (e != hipSuccess) return fail_hip(e, "rtk_trace_rays");
+  ctx->last_stream = st;
+  ctx->have_timing = true;
+  return RTK_OK;
+}
+
+int rtk_untile(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t world, uint64_t slot_pixels,
+               const float* d_rgb_f32_compact, float* d_rgb_f32_frame, const uint8_t* d_rgba8_compact,
+               uint8_t* d_rgba8_frame, void* hip_stream) {
+  if (!ctx || width == 0 || height == 0 || world == 0) return fail(RTK_ERR_INVALID, "rtk_untile: bad argument");
+  if ((d_rgb_f32_compact == nullptr) != (d_rgb_f32_frame == nullptr) || (d_rgba8_compact == nullptr) != (d_rgba8_frame == nullptr))
+    return fail(RTK_ERR_INVALID, "rtk_untile: compact and frame pointers must come in pairs");
+  for (uint32_t r = 0; r < world; ++r)
+    if (rtk_compact_pixels(width, height, r, world) > slot_pixels)
+      return fail(RTK_ERR_INVALID, "rtk_untile: slot_pixels smaller than a rank's compact buffer");
+  RTK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  RTK_HIP(rtk::launch_untile(st, width, height, world, slot_pixels, d_rgb_f32_compact, d_rgb_f32_frame, d_rgba8_compact,
+                             d_rgba8_frame));
+  return RTK_OK;
+}
+
+}  // extern "C"

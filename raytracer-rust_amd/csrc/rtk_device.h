@@ -1,0 +1,86 @@
+// rtk_device.h -- data layout shared by the host side (rtk_api.hip) and the kernels
+// (rtk_kernels.hip).  Everything here lives in HBM and is read-only during a render.
+#ifndef RTK_DEVICE_H
+#define RTK_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtk {
+
+constexpr int kBlock = 256;      // threads per workgroup = one 32x8 pixel tile (4 waves of 8x8)
+constexpr int kChunk = 1024;     // sphere filter records staged in LDS per pass (16 KiB)
+constexpr int kGroup = 8;        // records per wavefront early-out branch
+constexpr int kMaxDepth = 8;     // == RTK_MAX_DEPTH_LIMIT
+constexpr int kMaxLightBatch = 8;
+
+constexpr float kEps32 = 5.9604645e-8f;  // 2^-24, unit round-off of FP32
+
+// One scene object in f64: what the exact intersection test and the shading need.
+// `inv` holds rows 0..2 of the inverse transform (row 3 is 0 0 0 1 for the affine
+// transforms the library accepts).  Objects keep the caller's order: the index in this
+// array is the object's identity for tie-breaks (src/scene.rs:325-340, 164-166).
+struct DevObject {
+  double inv[12];
+  double color_a[3];
+  double color_b[3];
+  double ambient, diffuse, specular, shininess;
+  double transparency, reflectivity, refractivity;
+  double plane_normal[3];
+  uint32_t kind;
+  uint32_t texture_kind;
+};
+
+struct DevLight {
+  double pos[4];  // position incl. the reference's w (src/scene/lighting.rs:8-11)
+  double intensity[3];
+  double reserved_;
+};
+
+// Sphere record of the FP32 filter used by shadow and secondary rays:
+//   x, y, z : bounding-sphere centre minus DevScene::center, rounded to FP32
+//   w       : inflated squared radius (covers centre rounding), rounded up
+// Record of the primary-ray filter (rebuilt per camera by prep_primary_kernel):
+//   x, y, z : centre minus camera origin;  w : |L|^2 (1 - slack) - R'^2, rounded down
+// Both arrays are padded to a multiple of kGroup with records no ray can pass.
+struct DevScene {
+  const DevObject* objects;
+  const DevLight* lights;
+  const float4* sph_filter;
+  const double4* sph_exact;     // centre (world, f64) and bounding radius per filter record
+  const uint32_t* sph_object;   // filter record -> object index
+  const uint32_t* plane_object; // plane list -> object index
+  uint32_t n_objects, n_lights, n_spheres, n_spheres_padded, n_planes;
+  uint32_t max_depth;
+  uint32_t track_n1;     // some transparent object has refractivity != the others: keep n1
+  uint32_t any_secondary; // some material reflects or transmits: rays recurse
+  double center[3];      // recentring offset of the FP32 filter
+  double ambient[3];
+  float r2_max;          // max inflated squared radius
+  float r_max;           // max inflated radius
+  float c_max;           // max |centre - center|
+  float pad_;
+};
+
+struct DevCamera {
+  uint32_t width, height;
+  double half_width, half_height, pixel_size;
+  double inv[12];     // rows 0..2 of the inverse camera transform (hoisted out of the pixel loop)
+  double origin[3];   // inverse * point(0,0,0)
+};
+
+struct DevCounters {
+  unsigned long long rays_primary, rays_shadow, rays_secondary, exact_tests;
+};
+
+struct RenderTarget {
+  float* rgb;        // may be null
+  uint8_t* rgba8;    // may be null
+  uint32_t tiles_x, tiles_y;
+  uint32_t rank, world;  // this launch renders tiles t with t % world == rank
+  uint32_t n_local_tiles;
+  uint32_t compact;  // 1: tile-major compact layout, 0: row-major frame
+};
+
+}  // namespace rtk
+#endif

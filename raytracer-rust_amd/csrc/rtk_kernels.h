@@ -1,0 +1,28 @@
+// rtk_kernels.h -- launch wrappers implemented in rtk_kernels.hip.
+#ifndef RTK_KERNELS_H
+#define RTK_KERNELS_H
+
+#include "rtk_device.h"
+
+namespace rtk {
+
+// Lights fused per shadow sweep for a scene with n_lights lights (1, 2, 4 or 8).
+int light_batch_for(uint32_t n_lights);
+
+// Rebuilds the primary-ray filter records for camera C into prim[n_spheres_padded].
+hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamera& C, float4* prim);
+
+// Renders the tiles selected by T.
+hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim, const RenderTarget& T,
+                         DevCounters* counters);
+
+// Traces n caller-supplied rays (device pointers, n x 4 doubles in, n x 3 doubles out).
+hipError_t launch_trace_rays(hipStream_t st, const DevScene& S, const double* origins, const double* directions, uint64_t n,
+                             double* colors, DevCounters* counters);
+
+// Compact per-rank tile buffers -> row-major frame.
+hipError_t launch_untile(hipStream_t st, uint32_t width, uint32_t height, uint32_t world, uint64_t slot_pixels,
+                         const float* rgb_c, float* rgb_f, const uint8_t* px_c, uint8_t* px_f);
+
+}  // namespace rtk
+#endif

@@ -1,0 +1,186 @@
+"""Binding of the HIP device library (csrc/librtk.so) and the device-side render calls.
+
+There is no fallback: if the library is missing or no gfx950 device is present, the
+calls raise.  torch is used only to own device memory and the stream.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+from .canvas import Canvas
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librtk.so")
+
+
+class RtkError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"rtk error {code}: {message}")
+        self.code = code
+
+
+def build_library(force=False):
+    """Compiles csrc/librtk.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "librtk.so"]
+    if force:
+        cmd.insert(1, "-B")
+    subprocess.run(cmd, check=True, capture_output=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the renderer has no CPU fallback)")
+        _lib = abi.bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def _check(rc):
+    if rc != abi.RTK_OK:
+        raise RtkError(rc, library().rtk_last_error().decode())
+
+
+def camera_init(width, height, field_of_view):
+    cam = abi.rtk_camera()
+    _check(library().rtk_camera_init(C.byref(cam), width, height, field_of_view))
+    return cam
+
+
+def tiles_for_rank(width, height, rank, world):
+    return int(library().rtk_tiles_for_rank(width, height, rank, world))
+
+
+def compact_pixels(width, height, rank, world):
+    return int(library().rtk_compact_pixels(width, height, rank, world))
+
+
+class SceneHandle:
+    def __init__(self, device, handle, scene_abi):
+        self.device, self.handle, self._keep = device, handle, scene_abi
+
+    def release(self):
+        if self.handle:
+            library().rtk_scene_release(self.device.ctx, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class Device:
+    """One rtk_context bound to one HIP device."""
+
+    def __init__(self, index=0):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the renderer needs an MI355X (there is no CPU fallback)")
+        self.torch = torch
+        self.index = index
+        self.tdev = torch.device("cuda", index)
+        ctx = C.c_void_p()
+        _check(library().rtk_create(index, C.byref(ctx)))
+        self.ctx = ctx
+
+    def close(self):
+        if self.ctx:
+            library().rtk_destroy(self.ctx)
+            self.ctx = None
+
+    # ---- scenes -----------------------------------------------------------------
+    def upload(self, scene):
+        s = scene.to_abi() if hasattr(scene, "to_abi") else scene
+        h = C.c_void_p()
+        _check(library().rtk_scene_upload(self.ctx, C.byref(s), C.byref(h)))
+        return SceneHandle(self, h, s)
+
+    # ---- rendering ----------------------------------------------------------------
+    def render_device(self, handle, camera, rank=0, world=1, want_rgb=True, want_rgba8=True, out_rgb=None,
+                      out_rgba8=None):
+        """Asynchronous render into torch tensors on this device (current torch stream).
+        world == 1: [H, W, 3] float32 / [H, W, 4] uint8; world > 1: compact [pixels, 3] / [pixels, 4]."""
+        torch = self.torch
+        cam = camera.to_abi() if hasattr(camera, "to_abi") else camera
+        if world == 1:
+            shape3, shape4 = (cam.height, cam.width, 3), (cam.height, cam.width, 4)
+        else:
+            n = compact_pixels(cam.width, cam.height, rank, world)
+            shape3, shape4 = (n, 3), (n, 4)
+        rgb = rgba = None
+        if want_rgb:
+            rgb = out_rgb if out_rgb is not None else torch.empty(shape3, dtype=torch.float32, device=self.tdev)
+        if want_rgba8:
+            rgba = out_rgba8 if out_rgba8 is not None else torch.empty(shape4, dtype=torch.uint8, device=self.tdev)
+        tiling = abi.rtk_tiling(rank, world)
+        stream = torch.cuda.current_stream(self.tdev).cuda_stream
+        _check(library().rtk_render_device(
+            self.ctx, handle.handle, C.byref(cam), C.byref(tiling),
+            C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
+            C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
+            C.c_void_p(stream)))
+        return rgb, rgba
+
+    def stats(self):
+        st = abi.rtk_stats()
+        _check(library().rtk_get_stats(self.ctx, C.byref(st)))
+        return st
+
+    def render(self, scene, camera):
+        """`Camera::render` through the host-buffer entry point; returns a Canvas."""
+        s = scene.to_abi() if hasattr(scene, "to_abi") else scene
+        cam = camera.to_abi() if hasattr(camera, "to_abi") else camera
+        rgb = np.empty((cam.height, cam.width, 3), dtype=np.float32)
+        rgba = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
+        st = abi.rtk_stats()
+        _check(library().rtk_render(self.ctx, C.byref(s), C.byref(cam), rgb.ctypes.data_as(C.c_void_p),
+                                    rgba.ctypes.data_as(C.c_void_p), C.byref(st)))
+        return Canvas(cam.width, cam.height, rgb, rgba, st)
+
+    def trace(self, handle, origins, directions):
+        """`Scene::trace` for rays given as [n, 4] float64 arrays; returns [n, 3] float64."""
+        o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 4)
+        d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 4)
+        out = np.empty((o.shape[0], 3), dtype=np.float64)
+        _check(library().rtk_trace_rays(self.ctx, handle.handle, o.ctypes.data_as(C.c_void_p),
+                                        d.ctypes.data_as(C.c_void_p), o.shape[0], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def untile(self, width, height, world, slot_pixels, rgb_compact=None, rgba8_compact=None):
+        torch = self.torch
+        rgb = rgba = None
+        if rgb_compact is not None:
+            rgb = torch.empty((height, width, 3), dtype=torch.float32, device=self.tdev)
+        if rgba8_compact is not None:
+            rgba = torch.empty((height, width, 4), dtype=torch.uint8, device=self.tdev)
+        stream = torch.cuda.current_stream(self.tdev).cuda_stream
+        _check(library().rtk_untile(
+            self.ctx, width, height, world, slot_pixels,
+            C.c_void_p(rgb_compact.data_ptr()) if rgb_compact is not None else None,
+            C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
+            C.c_void_p(rgba8_compact.data_ptr()) if rgba8_compact is not None else None,
+            C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
+            C.c_void_p(stream)))
+        return rgb, rgba
+
+
+_default = None
+
+
+def default_device():
+    global _default
+    if _default is None:
+        _default = Device(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default

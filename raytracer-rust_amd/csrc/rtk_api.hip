@@ -348,7 +348,10 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   float r2_max = 0.f, r_max = 0.f, c_max = 0.f;
   for (uint32_t i = 0; i < n_pad; ++i) {
     if (i >= n_sph) {
-      filter[i] = make_float4(0.f, 0.f, 0.f, -1.0e30f);  // h^2 - (k|u|^2 + 1e30) never reaches the threshold
+      // padding repeats the last real record (and its object index): a repeated candidate is
+      // re-evaluated to the same roots, which changes no closest-hit or shadow decision
+      filter[i] = filter[n_sph - 1];
+      sph_object.push_back(sph_object[n_sph - 1]);
       continue;
     }
     const double c[3] = {sph_exact[i].x - center[0], sph_exact[i].y - center[1], sph_exact[i].z - center[2]};

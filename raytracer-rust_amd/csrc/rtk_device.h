@@ -42,7 +42,8 @@ struct DevLight {
 //   w       : inflated squared radius (covers centre rounding), rounded up
 // Record of the primary-ray filter (rebuilt per camera by prep_primary_kernel):
 //   x, y, z : centre minus camera origin;  w : |L|^2 (1 - slack) - R'^2, rounded down
-// Both arrays are padded to a multiple of kGroup with records no ray can pass.
+// Both arrays (and sph_object) are padded to a multiple of kGroup by repeating the last
+// real record; testing a sphere twice changes no decision.
 struct DevScene {
   const DevObject* objects;
   const DevLight* lights;

@@ -748,11 +748,8 @@ __global__ void __launch_bounds__(kBlock) trace_rays_kernel(DevScene S, const do
 __global__ void __launch_bounds__(kBlock) prep_primary_kernel(DevScene S, DevCamera C, float4* __restrict__ prim) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= S.n_spheres_padded) return;
-  if (i >= S.n_spheres) {
-    prim[i] = make_float4(0.f, 0.f, 0.f, 1.0e30f);  // (L.d)^2 >= 1e30 never holds
-    return;
-  }
-  const double4 s = S.sph_exact[i];
+  // padding records repeat the last real sphere (see rtk_scene_upload)
+  const double4 s = S.sph_exact[min(i, S.n_spheres - 1u)];
   const double Lx = s.x - C.origin[0], Ly = s.y - C.origin[1], Lz = s.z - C.origin[2];
   const double LL = Lx * Lx + Ly * Ly + Lz * Lz;
   const double eps = (double)kEps32;

@@ -158,13 +158,15 @@ class Device:
                                         d.ctypes.data_as(C.c_void_p), o.shape[0], out.ctypes.data_as(C.c_void_p)))
         return out
 
-    def untile(self, width, height, world, slot_pixels, rgb_compact=None, rgba8_compact=None):
+    def untile(self, width, height, world, slot_pixels, rgb_compact=None, rgba8_compact=None, out_rgb=None,
+               out_rgba8=None):
+        """Compact per-rank tile buffers laid end to end -> row-major frames (device tensors)."""
         torch = self.torch
         rgb = rgba = None
         if rgb_compact is not None:
-            rgb = torch.empty((height, width, 3), dtype=torch.float32, device=self.tdev)
+            rgb = out_rgb if out_rgb is not None else torch.empty((height, width, 3), dtype=torch.float32, device=self.tdev)
         if rgba8_compact is not None:
-            rgba = torch.empty((height, width, 4), dtype=torch.uint8, device=self.tdev)
+            rgba = out_rgba8 if out_rgba8 is not None else torch.empty((height, width, 4), dtype=torch.uint8, device=self.tdev)
         stream = torch.cuda.current_stream(self.tdev).cuda_stream
         _check(library().rtk_untile(
             self.ctx, width, height, world, slot_pixels,

@@ -1,0 +1,152 @@
+"""Multi-GPU frames: tile partition, gather to rank 0, de-interleave.
+
+Pixels are independent (the reference's loop has no cross-iteration state,
+src/scene/cameras.rs:75-82), so the frame shards with no data-path collective: rank r of
+`world` renders the 32x8 tiles t with t % world == r (round-robin keeps sky and ground
+tiles evenly mixed).  The only exchange is one gather of the compact tile buffers to rank 0
+per frame -- over xGMI through RCCL when the process group's backend is "nccl" -- followed
+by one de-interleave kernel on rank 0.
+
+One process per GPU; the process group is the caller's (`torch.distributed`).
+The render and the de-interleave step are injectable so that the partition and gather
+logic can be exercised on CPU with the `gloo` backend.
+"""
+import numpy as np
+
+from . import abi
+
+TILE_W, TILE_H = abi.RTK_TILE_W, abi.RTK_TILE_H
+TILE_PIXELS = TILE_W * TILE_H
+
+
+def tile_grid(width, height):
+    return (width + TILE_W - 1) // TILE_W, (height + TILE_H - 1) // TILE_H
+
+
+def tiles_for_rank(width, height, rank, world):
+    tx, ty = tile_grid(width, height)
+    n = tx * ty
+    return n // world + (1 if (n % world) > rank else 0)
+
+
+def slot_pixels(width, height, world):
+    """Pixels per gather slot: the largest compact buffer (rank 0 owns the most tiles)."""
+    return tiles_for_rank(width, height, 0, world) * TILE_PIXELS
+
+
+def tile_rect(width, height, tile):
+    """Pixel rectangle (x0, y0, x1, y1) of a global tile index, clipped to the frame."""
+    tx, _ = tile_grid(width, height)
+    x0, y0 = (tile % tx) * TILE_W, (tile // tx) * TILE_H
+    return x0, y0, min(x0 + TILE_W, width), min(y0 + TILE_H, height)
+
+
+def untile_host(width, height, world, slot, compact, channels):
+    """Reference de-interleave on the host: `compact` is [world * slot, channels]."""
+    compact = np.asarray(compact).reshape(world * slot, channels)
+    frame = np.zeros((height, width, channels), dtype=compact.dtype)
+    tx, ty = tile_grid(width, height)
+    for tile in range(tx * ty):
+        rank, k = tile % world, tile // world
+        x0, y0, x1, y1 = tile_rect(width, height, tile)
+        block = compact[rank * slot + k * TILE_PIXELS: rank * slot + (k + 1) * TILE_PIXELS].reshape(TILE_H, TILE_W, channels)
+        frame[y0:y1, x0:x1] = block[: y1 - y0, : x1 - x0]
+    return frame
+
+
+class DistributedRenderer:
+    """Renders a frame over the ranks of a torch.distributed process group.
+
+    render_compact(rank, world, out_rgb, out_rgba8): fills this rank's buffers (torch
+        tensors [slot, 3] float32 and [slot, 4] uint8; either may be None) -- compact
+        tile-major layout when world > 1, the row-major frame itself (first W*H pixels)
+        when world == 1, exactly as rtk_render_device lays them out.
+    untile(gathered_rgb, gathered_rgba8): rank-0 only, world > 1; [world*slot, c] -> frames.
+    """
+
+    def __init__(self, width, height, group=None, want_rgb=True, want_rgba8=True, tensor_device=None,
+                 render_compact=None, untile=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.width, self.height = width, height
+        self.slot = slot_pixels(width, height, self.world)
+        self.want_rgb, self.want_rgba8 = want_rgb, want_rgba8
+        self.render_compact, self.untile = render_compact, untile
+        dev = tensor_device if tensor_device is not None else torch.device("cpu")
+        # fixed buffers: nothing is allocated per frame
+        self.rgb = torch.zeros((self.slot, 3), dtype=torch.float32, device=dev) if want_rgb else None
+        self.rgba8 = torch.zeros((self.slot, 4), dtype=torch.uint8, device=dev) if want_rgba8 else None
+        self.g_rgb = self.g_rgba8 = None
+        if self.rank == 0 and self.world > 1:
+            if want_rgb:
+                self.g_rgb = torch.zeros((self.world * self.slot, 3), dtype=torch.float32, device=dev)
+            if want_rgba8:
+                self.g_rgba8 = torch.zeros((self.world * self.slot, 4), dtype=torch.uint8, device=dev)
+
+    def _gather(self, local, gathered):
+        if local is None:
+            return
+        if self.rank == 0:
+            chunks = list(gathered.view(self.world, *local.shape).unbind(0))
+            self.dist.gather(local, gather_list=chunks, dst=0, group=self.group)
+        else:
+            self.dist.gather(local, gather_list=None, dst=0, group=self.group)
+
+    def frame(self):
+        """One frame.  Returns (rgb, rgba8) frames on rank 0, (None, None) elsewhere."""
+        self.render_compact(self.rank, self.world, self.rgb, self.rgba8)
+        if self.world == 1:
+            n = self.width * self.height
+            rgb = self.rgb[:n].view(self.height, self.width, 3) if self.rgb is not None else None
+            rgba8 = self.rgba8[:n].view(self.height, self.width, 4) if self.rgba8 is not None else None
+            return rgb, rgba8
+        self._gather(self.rgb, self.g_rgb)
+        self._gather(self.rgba8, self.g_rgba8)
+        if self.rank != 0:
+            return None, None
+        return self.untile(self.g_rgb, self.g_rgba8)
+
+
+def gpu_renderer(device, handle, camera, group=None, want_rgb=True, want_rgba8=True):
+    """DistributedRenderer wired to the HIP path: compact tile render + device untile."""
+    cam = camera.to_abi() if hasattr(camera, "to_abi") else camera
+    w, h = cam.width, cam.height
+
+    def render_compact(rank, world, out_rgb, out_rgba8):
+        _render_compact(device, handle, cam, rank, world, out_rgb, out_rgba8)
+
+    frames = {}
+
+    def untile(g_rgb, g_rgba8):
+        import torch.distributed as dist
+
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        torch = device.torch
+        if g_rgb is not None and "rgb" not in frames:
+            frames["rgb"] = torch.empty((h, w, 3), dtype=torch.float32, device=device.tdev)
+        if g_rgba8 is not None and "rgba8" not in frames:
+            frames["rgba8"] = torch.empty((h, w, 4), dtype=torch.uint8, device=device.tdev)
+        return device.untile(w, h, world, slot_pixels(w, h, world), g_rgb, g_rgba8, frames.get("rgb"),
+                             frames.get("rgba8"))
+
+    return DistributedRenderer(w, h, group, want_rgb, want_rgba8, device.tdev, render_compact, untile)
+
+
+def _render_compact(device, handle, cam, rank, world, out_rgb, out_rgba8):
+    import ctypes as C
+
+    from . import device as _device
+
+    lib = _device.library()
+    tiling = abi.rtk_tiling(rank, max(world, 1))
+    stream = device.torch.cuda.current_stream(device.tdev).cuda_stream
+    _device._check(lib.rtk_render_device(
+        device.ctx, handle.handle, C.byref(cam), C.byref(tiling),
+        C.c_void_p(out_rgb.data_ptr()) if out_rgb is not None else None,
+        C.c_void_p(out_rgba8.data_ptr()) if out_rgba8 is not None else None,
+        C.c_void_p(stream)))

@@ -1,0 +1,99 @@
+"""The multi-rank frame path on CPU: two gloo ranks each produce their tiles (with the CPU
+oracle standing in for the device render), gather to rank 0 and de-interleave.  The frame
+must equal the single-rank frame bit for bit -- tiles are independent
+(src/scene/cameras.rs:75-82 has no cross-iteration state)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as tdist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, w, h, out_path):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    rtk = importlib.import_module("raytracer-rust_amd")
+    rdist = importlib.import_module("raytracer-rust_amd.dist")
+    import oracle_binding as ob
+
+    scene, camera = rtk.synthetic.config("C2g", w, h)
+
+    def render_compact(r, wd, out_rgb, out_rgba8):
+        # what rtk_render_device writes for tiling {r, wd}: local tile k = global tile k*wd + r
+        tx, ty = rdist.tile_grid(w, h)
+        out_rgb.zero_()
+        out_rgba8.zero_()
+        k = 0
+        for tile in range(r, tx * ty, wd):
+            x0, y0, x1, y1 = rdist.tile_rect(w, h, tile)
+            rgb, rgba, _ = ob.render(scene, camera, rect=(x0, y0, x1, y1))
+            block3 = np.zeros((rdist.TILE_H, rdist.TILE_W, 3), np.float32)
+            block4 = np.zeros((rdist.TILE_H, rdist.TILE_W, 4), np.uint8)
+            block3[: y1 - y0, : x1 - x0] = rgb.astype(np.float32)
+            block4[: y1 - y0, : x1 - x0] = rgba
+            out_rgb[k * 256:(k + 1) * 256] = torch.from_numpy(block3.reshape(256, 3))
+            out_rgba8[k * 256:(k + 1) * 256] = torch.from_numpy(block4.reshape(256, 4))
+            k += 1
+        assert k == rdist.tiles_for_rank(w, h, r, wd)
+
+    def untile(g_rgb, g_rgba8):
+        slot = rdist.slot_pixels(w, h, world)
+        return (rdist.untile_host(w, h, world, slot, g_rgb.numpy(), 3), rdist.untile_host(w, h, world, slot, g_rgba8.numpy(), 4))
+
+    renderer = rdist.DistributedRenderer(w, h, render_compact=render_compact, untile=untile)
+    assert renderer.world == world and renderer.rank == rank
+    rgb, rgba = renderer.frame()
+    if rank == 0:
+        np.savez(out_path, rgb=rgb, rgba=rgba)
+    else:
+        assert rgb is None and rgba is None
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("w,h", [(96, 40), (70, 19)])
+def test_two_rank_frame_equals_single_rank(rtk, oracle, tmp_path, w, h):
+    world = 2
+    out = str(tmp_path / "frame.npz")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, out), nprocs=world, join=True)
+    got = np.load(out)
+    scene, camera = rtk.synthetic.config("C2g", w, h)
+    rgb, rgba, _ = oracle.render(scene, camera)
+    assert np.array_equal(got["rgba"], rgba)
+    assert np.array_equal(got["rgb"], rgb.astype(np.float32))
+
+
+def test_untile_host_round_trip(rtk):
+    rdist = importlib.import_module("raytracer-rust_amd.dist")
+    rng = np.random.default_rng(0)
+    for w, h, world in [(33, 9, 3), (64, 16, 2), (100, 37, 8), (5, 5, 4)]:
+        frame = rng.integers(0, 255, size=(h, w, 4), dtype=np.uint8)
+        slot = rdist.slot_pixels(w, h, world)
+        compact = np.zeros((world * slot, 4), np.uint8)
+        tx, ty = rdist.tile_grid(w, h)
+        for tile in range(tx * ty):
+            r, k = tile % world, tile // world
+            x0, y0, x1, y1 = rdist.tile_rect(w, h, tile)
+            block = np.zeros((rdist.TILE_H, rdist.TILE_W, 4), np.uint8)
+            block[: y1 - y0, : x1 - x0] = frame[y0:y1, x0:x1]
+            compact[r * slot + k * 256: r * slot + (k + 1) * 256] = block.reshape(256, 4)
+        assert np.array_equal(rdist.untile_host(w, h, world, slot, compact, 4), frame)

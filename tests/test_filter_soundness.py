@@ -1,0 +1,151 @@
+"""The FP32 candidate filter must never drop a (ray, sphere) pair the reference's f64
+test accepts.  The device arithmetic is modelled in numpy float32 (tests/filter_model.py);
+the f64 side is the reference's object-space quadratic (src/scene/shapes/spheres.rs:18-35
+behind src/scene.rs:75-84), cross-checked against the CPU oracle on a subsample.
+
+Adversarial inputs: for every (ray, sphere centre) pair the radius is tuned by bisection
+to the grazing radius R* (discriminant = 0) and the filter is asked about R*(1 + delta)
+for tiny positive delta, i.e. rays that only just touch.
+"""
+import numpy as np
+import pytest
+
+from filter_model import FilterScene
+
+
+def exact_disc(p, d, dw, c, R):
+    """Discriminant of the reference's quadratic for a sphere translate(c) * scale(R)."""
+    R = np.asarray(R, np.float64)[..., None]
+    dw = np.asarray(dw, np.float64)
+    oo = (p - c) / R
+    dd = (d - c * dw[..., None]) / R
+    a = (dd * dd).sum(axis=-1) + dw * dw
+    b = 2.0 * (oo * dd).sum(axis=-1)
+    cc = (oo * oo).sum(axis=-1) - 1.0
+    return b * b - 4.0 * a * cc
+
+
+def grazing_radius(p, d, dw, c):
+    """Smallest radius with a real root, by bisection on the exact discriminant."""
+    lo = np.zeros(len(p)) + 1e-9
+    hi = np.sqrt(((p - c) ** 2).sum(axis=-1)) * 1.5 + 1.0
+    assert (exact_disc(p, d, dw, c, hi) >= 0).all()
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        hit = exact_disc(p, d, dw, c, mid) >= 0
+        hi = np.where(hit, mid, hi)
+        lo = np.where(hit, lo, mid)
+    return hi
+
+
+DELTAS = (1e-13, 1e-10, 1e-8, 1e-6, 1e-4, 1e-2, 0.5)
+
+
+def _unit(v):
+    return v / np.sqrt((v * v).sum(axis=-1, keepdims=True))
+
+
+@pytest.mark.parametrize("scale", [1.0, 30.0, 300.0, 3000.0])
+def test_primary_filter_keeps_every_grazing_hit(scale):
+    rng = np.random.default_rng(int(scale))
+    n = 20000
+    origin = rng.normal(size=3) * scale * 0.3
+    c = origin + _unit(rng.normal(size=(n, 3))) * rng.uniform(0.5, 1.0, size=(n, 1)) * scale * rng.uniform(0.05, 1, size=(n, 1))
+    # aim near the limb of a ball of radius ~r0
+    r0 = rng.uniform(0.05, 2.0, size=n)
+    toward = c - origin
+    perp = _unit(np.cross(toward, rng.normal(size=(n, 3))))
+    d = _unit(toward + perp * r0[:, None])
+    p = np.broadcast_to(origin, (n, 3))
+    Rstar = grazing_radius(p, d, np.zeros(n), c)
+    for delta in DELTAS:
+        R = Rstar * (1.0 + delta)
+        hit = exact_disc(p, d, np.zeros(n), c, R) >= 0
+        fs = FilterScene(c, R)
+        keep = fs.primary_pass(origin, d, pairwise=True)
+        assert not (hit & ~keep).any(), f"dropped {int((hit & ~keep).sum())} grazing hits at delta={delta}"
+        assert delta < 1e-6 or hit.mean() > 0.9  # below that the f64 discriminant itself is rounding noise
+
+
+@pytest.mark.parametrize("light_w", [0.0, 1.0, 0.5])
+@pytest.mark.parametrize("scale", [2.0, 50.0, 400.0])
+def test_shadow_filter_keeps_every_grazing_hit(scale, light_w):
+    rng = np.random.default_rng(int(scale * 10 + light_w * 3))
+    n = 20000
+    p = rng.normal(size=(n, 3)) * scale * 0.4
+    L = np.array([0.3, 1.0, -0.2]) * scale + rng.normal(size=3)
+    # sphere centres scattered around the segment p -> light and beyond
+    s = rng.uniform(-0.5, 1.5, size=(n, 1))
+    c = p + (L - p) * s + rng.normal(size=(n, 3)) * rng.uniform(0.01, 3.0, size=(n, 1))
+    lv = L - p
+    lw = light_w - 1.0
+    m = np.sqrt((lv * lv).sum(axis=1) + lw * lw)
+    d, dw = lv / m[:, None], lw / m
+    Rstar = grazing_radius(p, d, dw, c)
+    G = L - light_w * p
+    for delta in DELTAS:
+        R = Rstar * (1.0 + delta)
+        hit = exact_disc(p, d, dw, c, R) >= 0
+        fs = FilterScene(c, R)
+        keep = fs.general_pass(p, G, np.full(n, lw), pairwise=True)
+        assert not (hit & ~keep).any(), f"dropped {int((hit & ~keep).sum())} at delta={delta}"
+        assert delta < 1e-6 or hit.mean() > 0.9  # below that the f64 discriminant itself is rounding noise
+
+
+def test_secondary_ray_filter_with_unnormalised_directions():
+    rng = np.random.default_rng(7)
+    n = 20000
+    p = rng.normal(size=(n, 3)) * 40.0
+    d = rng.normal(size=(n, 3)) * rng.uniform(0.01, 20.0, size=(n, 1))  # refraction directions are not unit
+    c = p + d * rng.uniform(-3, 3, size=(n, 1)) + rng.normal(size=(n, 3)) * rng.uniform(0.01, 2.0, size=(n, 1))
+    Rstar = grazing_radius(p, d, np.zeros(n), c)
+    for delta in DELTAS:
+        R = Rstar * (1.0 + delta)
+        hit = exact_disc(p, d, np.zeros(n), c, R) >= 0
+        keep = FilterScene(c, R).general_pass(p, d, np.zeros(n), pairwise=True)
+        assert not (hit & ~keep).any()
+
+
+def test_exact_model_agrees_with_the_oracle(rtk, oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        c, R = rng.normal(size=3) * 5, rng.uniform(0.2, 2.0)
+        p, d = rng.normal(size=3) * 5, rng.normal(size=3)
+        dw = rng.choice([0.0, -0.1, 0.3])
+        node = rtk.Sphere().with_transform(rtk.Matrix4x4.translate(*c) * rtk.Matrix4x4.scale(R, R, R))
+        roots = oracle.object_intersect(node, (*p, 1.0), (*d, dw))
+        disc = exact_disc(p[None], d[None], np.array([dw]), c[None], np.array([R]))[0]
+        assert (len(roots) == 2) == (disc >= 0) or abs(disc) < 1e-9
+
+
+def test_filter_stays_selective_on_a_c4_like_scene(rtk):
+    """Regression guard for speed: on the 10k-sphere layout the filter keeps only a small
+    multiple of the true hits (every kept pair costs an f64 re-evaluation)."""
+    scene, camera = rtk.synthetic.config("C4", 64, 36)
+    spheres = [n for n in scene.nodes if n.kind == rtk.abi.RTK_SPHERE]
+    c = np.array([[n.transform.e[3], n.transform.e[7], n.transform.e[11]] for n in spheres])
+    R = np.array([n.transform.e[0] for n in spheres])
+    fs = FilterScene(c, R)
+    rng = np.random.default_rng(1)
+    # camera rays through random pixels
+    inv = np.linalg.inv(np.array(camera.transform.e).reshape(4, 4))
+    origin = inv[:3, 3]
+    xs, ys = rng.uniform(0, camera.width, 256), rng.uniform(camera.height * 0.3, camera.height, 256)
+    px = np.stack([camera.half_width - xs * camera.pixel_size, camera.half_height - ys * camera.pixel_size,
+                   -np.ones(256), np.ones(256)], axis=1)
+    d = _unit((inv @ px.T).T[:, :3] - origin)
+    keep = fs.primary_pass(origin, d)
+    hit = np.stack([exact_disc(np.broadcast_to(origin, (len(c), 3)), np.broadcast_to(di, (len(c), 3)), np.zeros(len(c)), c, R) >= 0
+                    for di in d])
+    assert not (hit & ~keep).any()
+    assert keep.sum() <= 2.0 * hit.sum() + 64, (int(keep.sum()), int(hit.sum()))
+    # shadow rays from points on the floor towards the first light
+    L = np.array(scene.lights[0].position[:3])
+    p = np.stack([rng.uniform(-60, 60, 256), np.full(256, 1e-4), rng.uniform(0, 120, 256)], axis=1)
+    keep = fs.general_pass(p, np.broadcast_to(L, p.shape), np.full(256, -1.0))
+    lv = L - p
+    m = np.sqrt((lv * lv).sum(axis=1) + 1.0)
+    hit = np.stack([exact_disc(np.broadcast_to(p[i], (len(c), 3)), np.broadcast_to(lv[i] / m[i], (len(c), 3)),
+                               np.full(len(c), -1.0 / m[i]), c, R) >= 0 for i in range(256)])
+    assert not (hit & ~keep).any()
+    assert keep.sum() <= 2.0 * hit.sum() + 64, (int(keep.sum()), int(hit.sum()))

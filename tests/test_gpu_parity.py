@@ -1,0 +1,252 @@
+"""Parity of the HIP path against the CPU oracle and the reference's golden image.
+
+Every call goes through the C ABI (ctypes -> librtk.so).  Bars (north star): linear FP32
+colour within 1e-4 relative of the f64 result; 8-bit output within 1 LSB on >= 99.99 % of
+pixels.  The path decides everything on f64 values, so in practice frames come out
+bit-identical after the 8-bit cast; the tests also pin the ray counts, which must equal
+the oracle's exactly (one ray = one `Scene::intersect` call, src/scene.rs:146, 217).
+"""
+import hashlib
+import importlib
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from gpu_common import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(rtk):
+    device = importlib.import_module("raytracer-rust_amd.device")
+    d = device.Device(0)
+    yield d
+    d.close()
+
+
+def counts(st):
+    return (st.rays_primary, st.rays_shadow, st.rays_secondary)
+
+
+def check_against_oracle(dev, oracle, scene, camera, what, rect=None, expect_identical=True):
+    canvas = dev.render(scene, camera)
+    rgb, rgba, ost = oracle.render(scene, camera, rect=rect, threads=16)
+    g_rgb, g_rgba = canvas.rgb, canvas.rgba8
+    if rect:
+        x0, y0, x1, y1 = rect
+        g_rgb, g_rgba = g_rgb[y0:y1, x0:x1], g_rgba[y0:y1, x0:x1]
+    else:
+        assert counts(canvas.stats) == counts(ost), what
+    max_rel, bad_rel, bad_lsb, not_equal = assert_parity(g_rgb, g_rgba, rgb, rgba, what)
+    if expect_identical:
+        assert not_equal == 0, f"{what}: {not_equal} pixels differ after the 8-bit cast"
+        assert max_rel < 1e-6, f"{what}: max relative error {max_rel:.3e}"
+    assert (g_rgba[..., 3] == 255).all()
+    return canvas
+
+
+# ---------------------------------------------------------------- C1: the bundled scene
+def test_bundled_scene_matches_reference_image(rtk, dev, oracle, golden_dir):
+    scene = rtk.PackedScene.from_yaml_file(os.path.join(golden_dir, "test01.yaml")).build()
+    camera = rtk.Camera(1920, 1080, rtk.PI / 3.0)
+    canvas = check_against_oracle(dev, oracle, scene, camera, "C1")
+    meta = json.load(open(os.path.join(golden_dir, "output_meta.json")))
+    golden = np.load(os.path.join(golden_dir, "output_stride4.npy"))
+    d = np.abs(canvas.rgba8[::4, ::4, :3].astype(int) - golden.astype(int)).max(axis=2)
+    assert (d > 1).sum() <= int(d.size * 1e-4)
+    assert (d > 0).sum() == 0
+    assert hashlib.sha256(canvas.rgba8.tobytes()).hexdigest() == meta["decoded_rgba_sha256"]
+    assert canvas.stats.rays == 21939338
+
+
+# ---------------------------------------------------------------- synthetic configurations
+@pytest.mark.parametrize("name,w,h", [("C2", 1920, 1080), ("C2g", 960, 540), ("C3", 768, 432), ("C4", 256, 144),
+                                      ("C5", 192, 192)])
+def test_synthetic_config_reduced_resolution(rtk, dev, oracle, name, w, h):
+    scene, camera = rtk.synthetic.config(name, w, h)
+    check_against_oracle(dev, oracle, scene, camera, f"{name} {w}x{h}")
+
+
+@pytest.mark.parametrize("name,rect", [("C3", (1792, 1180, 2048, 1324)), ("C4", (1800, 1000, 1992, 1108)),
+                                       ("C4", (0, 2060, 160, 2160))])
+def test_full_size_frame_crop(rtk, dev, oracle, name, rect):
+    """BASELINE.json's full sizes (3840x2160): the whole frame is rendered on the device, a
+    rectangle of it is checked against the oracle."""
+    scene, camera = rtk.synthetic.config(name)
+    check_against_oracle(dev, oracle, scene, camera, f"{name} crop {rect}", rect=rect)
+
+
+def test_full_size_properties(rtk, dev):
+    """Size-independent properties at full size: determinism, alpha, ray-count identities."""
+    scene, camera = rtk.synthetic.config("C4")
+    a = dev.render(scene, camera)
+    b = dev.render(scene, camera)
+    assert np.array_equal(a.rgb, b.rgb) and np.array_equal(a.rgba8, b.rgba8)
+    assert counts(a.stats) == counts(b.stats)
+    st = a.stats
+    assert st.rays_primary == 3840 * 2160 and st.rays_secondary == 0
+    n_lights = len(scene.lights)
+    assert st.rays_primary <= st.rays_shadow + (a.rgba8[..., :3].max(axis=2) == 0).sum()  # every hit pixel casts >= 1 shadow ray
+    assert st.rays_shadow <= n_lights * st.rays_primary
+    # the cast is the reference's: truncation of colour * 255, saturated
+    v = np.clip(np.trunc(a.rgb.astype(np.float64) * 255.0), 0, 255).astype(np.uint8)
+    assert (np.abs(v.astype(int) - a.rgba8[..., :3].astype(int)) <= 1).all()
+
+
+# ---------------------------------------------------------------- Scene::trace known answers
+@pytest.fixture()
+def test_scene(rtk):
+    scene = rtk.Scene()
+    scene.add_light(rtk.PointLight(rtk.vec3(-10, 10, -10), rtk.WHITE))
+    scene.add_object(rtk.Sphere().with_material(
+        rtk.Material.default().with_color(rtk.rgb(0.8, 1.0, 0.6)).with_diffuse(0.7).with_specular(0.2)))
+    scene.add_object(rtk.Sphere().with_transform(rtk.Matrix4x4.scale(0.5, 0.5, 0.5)))
+    return scene
+
+
+def approx(a, b, eps=1e-5):
+    return all(abs(x - y) < eps for x, y in zip(a, b))
+
+
+def test_trace_known_answers(rtk, dev, test_scene):
+    h = dev.upload(test_scene)
+    # src/scene.rs:495-502
+    c = dev.trace(h, [(0, 0, -5, 1)], [(0, 0, 1, 0)])[0]
+    assert approx(c, (0.38012764, 0.47515953, 0.28509575))
+    # src/scene.rs:483-492: a miss returns the ambient colour
+    test_scene.ambient_color = rtk.RED
+    h2 = dev.upload(test_scene)
+    assert approx(dev.trace(h2, [(0, 0, -5, 1)], [(0, 1, 0, 0)])[0], rtk.RED)
+
+
+def test_trace_inside_and_shadow(rtk, dev, oracle, test_scene):
+    # src/scene.rs:466-480: light inside, ray from inside the inner sphere
+    test_scene.lights[0] = rtk.PointLight(rtk.point(0, 0.25, 0), rtk.WHITE)
+    h = dev.upload(test_scene)
+    o, d = (0, 0, 0, 1), (0, 0, 1, 0)
+    assert approx(dev.trace(h, [o], [d])[0], oracle.trace(test_scene, o, d), 1e-12)
+    # src/scene.rs:537-552
+    scene = rtk.Scene()
+    scene.add_light(rtk.PointLight(rtk.point(0, 0, -10), rtk.WHITE))
+    scene.add_object(rtk.Sphere())
+    scene.add_object(rtk.Sphere().with_transform(rtk.Matrix4x4.translate(0, 0, 10)))
+    h = dev.upload(scene)
+    o, d = (0, 0, 5, 1), (0, 0, 1, 0)
+    got = dev.trace(h, [o], [d])[0]
+    assert approx(got, (0.1, 0.1, 0.1)) and approx(got, oracle.trace(scene, o, d), 1e-12)
+
+
+def test_trace_reflection_known_answer(rtk, dev, oracle, test_scene):
+    # src/scene.rs:571-592: the reflected part of this ray is rgb(0.19007981, 0.23759975, 0.14255986)
+    test_scene.add_object(rtk.Plane(rtk.vec3(0, 1, 0)).with_material(rtk.Material.default().with_reflective(0.5))
+                          .with_transform(rtk.Matrix4x4.translate(0, -1, 0)))
+    h = dev.upload(test_scene)
+    s2 = math.sqrt(2.0)
+    o, d = (0, 0, -3, 1), (0, -s2 / 2, s2 / 2, 0)
+    got = dev.trace(h, [o], [d])[0]
+    want = oracle.trace(test_scene, o, d)
+    assert approx(got, want, 1e-12)
+    data = oracle.lighting_data(test_scene, o, d, [(2, s2)])
+    assert approx(oracle.reflected_color(test_scene, data), (0.19007981, 0.23759975, 0.14255986))
+
+
+def test_random_rays_through_glass(rtk, dev, oracle):
+    """Overlapping glass spheres with distinct refractive indices: exercises the n1/n2 rule
+    (src/scene/lighting.rs:81-116), total internal reflection and unnormalised secondary rays."""
+    rng = np.random.default_rng(11)
+    scene = rtk.Scene()
+    scene.add_light(rtk.PointLight(rtk.vec3(-4, 6, -8), rtk.WHITE))
+    scene.add_light(rtk.PointLight(rtk.point(5, 3, -2), rtk.rgb(0.3, 0.4, 0.5)))
+    scene.add_object(rtk.Plane().with_material(
+        rtk.Material.default().with_pattern(rtk.Texture.checker(rtk.WHITE, rtk.BLACK)).with_reflective(0.3))
+        .with_transform(rtk.Matrix4x4.translate(0, -1.5, 0)))
+    for i in range(12):
+        c = rng.normal(size=3) * 0.9
+        r = rng.uniform(0.5, 1.1)
+        m = (rtk.Material.default().with_color(tuple(rng.uniform(0.2, 1, 3))).with_diffuse(0.3)
+             .with_transparency(rng.choice([0.0, 0.6, 0.9])).with_reflective(rng.choice([0.0, 0.4, 0.9]))
+             .with_refractivity(rng.choice([1.0, 1.3, 1.5, 2.4])))
+        scene.add_object(rtk.Sphere().with_material(m).with_transform(
+            rtk.Matrix4x4.translate(*c) * rtk.Matrix4x4.scale(r, r, r)))
+    n = 4096
+    o = np.concatenate([rng.normal(size=(n, 3)) * 2.0, np.ones((n, 1))], axis=1)  # many origins lie inside spheres
+    d = rng.normal(size=(n, 3))
+    d = np.concatenate([d / np.linalg.norm(d, axis=1, keepdims=True), np.zeros((n, 1))], axis=1)
+    h = dev.upload(scene)
+    got = dev.trace(h, o, d)
+    want = np.array([oracle.trace(scene, tuple(o[i]), tuple(d[i])) for i in range(n)])
+    err = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+    assert (err.max(axis=1) > 1e-9).sum() <= 2, f"max {err.max():.3e}"
+
+
+# ---------------------------------------------------------------- shapes, textures, lights
+def test_general_affine_objects_and_all_textures(rtk, dev, oracle):
+    """Non-uniform scale, rotation and shear on spheres; rotated planes keep their untransformed
+    normal (src/scene/shapes/planes.rs:30-32); every texture kind; w = 0 and w = 1 lights."""
+    M = rtk.Matrix4x4
+    scene = rtk.Scene()
+    scene.add_light(rtk.PointLight(rtk.vec3(-10, 10, -10), rtk.rgb(0.7, 0.7, 0.7)))
+    scene.add_light(rtk.PointLight(rtk.point(6, 8, -6), rtk.rgb(0.5, 0.4, 0.3)))
+    mat = rtk.Material.default()
+    scene.add_object(rtk.Plane().with_material(mat.with_pattern(rtk.Texture.ring(rtk.WHITE, rtk.rgb(0.1, 0.3, 0.5)))))
+    scene.add_object(rtk.Plane().with_material(mat.with_pattern(rtk.Texture.striped(rtk.rgb(1, 0.5, 0), rtk.BLACK)))
+                     .with_transform(M.translate(0, 0, 12) * M.rotate_x(math.pi / 2)))
+    scene.add_object(rtk.Sphere().with_material(mat.with_pattern(rtk.Texture.gradient(rtk.RED, rtk.rgb(0, 0, 1))))
+                     .with_transform(M.translate(-2, 1, 1) * M.rotate_z(0.6) * M.scale(1.6, 0.5, 1.0)))
+    scene.add_object(rtk.Sphere().with_material(mat.with_pattern(rtk.Texture.checker(rtk.WHITE, rtk.rgb(0.2, 0.6, 0.2))))
+                     .with_transform(M.translate(2, 1.2, 0.5) * M.rotate_y(0.4) * M.rotate_x(-0.7) * M.scale(0.6, 1.2, 0.9)))
+    scene.add_object(rtk.Sphere().with_material(mat.with_color(rtk.rgb(0.9, 0.8, 0.2)).with_reflective(0.4))
+                     .with_transform(M.translate(0, 0.8, -1.0) * M.shear(0.4, 0, 0, 0.3, 0, 0) * M.scale(0.8, 0.8, 0.8)))
+    scene.add_object(rtk.Sphere().with_material(mat.with_color(rtk.rgb(0.3, 0.3, 0.9)))
+                     .with_transform(M.scale(1, 0, 1)))  # singular: identity inverse (src/scene.rs:55-62)
+    camera = rtk.Camera(640, 360, rtk.PI / 3.0)
+    check_against_oracle(dev, oracle, scene, camera, "affine+textures")
+
+
+def test_exotic_light_w_still_matches(rtk, dev, oracle):
+    """A light whose w is neither 0 nor 1 disables the filter's cull for its rays (every sphere is
+    evaluated in f64); results must still equal the oracle."""
+    scene, camera = rtk.synthetic.config("C2", 240, 135)
+    scene.lights[1] = rtk.PointLight(rtk.vec4(5, 30, -10, 2.5), rtk.rgb(0.5, 0.5, 0.5))
+    scene.lights[0] = rtk.PointLight(rtk.vec4(-8, 25, -4, 0.4), rtk.rgb(0.5, 0.5, 0.5))
+    check_against_oracle(dev, oracle, scene, camera, "exotic light w")
+
+
+def test_camera_inside_a_sphere_and_depth_limits(rtk, dev, oracle, golden_dir):
+    scene = rtk.PackedScene.from_yaml_file(os.path.join(golden_dir, "test01.yaml")).build()
+    camera = rtk.Camera(320, 180, rtk.PI / 2.0)
+    camera.transform = rtk.Matrix4x4.look_at(rtk.point(-0.5, 1.0, 0.4), rtk.point(1.5, 0.5, -0.5), rtk.vec3(0, 1, 0))
+    for depth in (0, 1, 2, 5, 8):
+        scene.max_depth = depth
+        check_against_oracle(dev, oracle, scene, camera, f"inside sphere, max_depth={depth}")
+
+
+@pytest.mark.parametrize("n_lights", [0, 1, 3, 5, 8, 11])
+def test_light_counts(rtk, dev, oracle, n_lights):
+    """Shadow sweeps fuse 1, 2, 4 or 8 lights; counts in between and beyond use padded / repeated batches."""
+    scene = rtk.synthetic.make_scene(40, True, n_lights, 1234)
+    camera = rtk.synthetic.make_camera(40, 320, 180)
+    check_against_oracle(dev, oracle, scene, camera, f"{n_lights} lights")
+
+
+# ---------------------------------------------------------------- frame shapes
+@pytest.mark.parametrize("w,h", [(1, 1), (31, 7), (33, 9), (100, 37), (257, 3)])
+def test_ragged_frames(rtk, dev, oracle, w, h):
+    scene, _ = rtk.synthetic.config("C2", 8, 8)
+    camera = rtk.synthetic.make_camera(64, w, h)
+    check_against_oracle(dev, oracle, scene, camera, f"{w}x{h}")
+
+
+def test_empty_scene_and_no_spheres(rtk, dev, oracle):
+    scene = rtk.Scene()
+    scene.ambient_color = rtk.rgb(0.25, 0.5, 0.75)
+    camera = rtk.Camera(64, 40, 1.0)
+    c = check_against_oracle(dev, oracle, scene, camera, "empty scene")
+    assert np.allclose(c.rgb, (0.25, 0.5, 0.75)) and counts(c.stats) == (64 * 40, 0, 0)
+    scene.add_light(rtk.PointLight(rtk.vec3(0, 5, 0)))
+    scene.add_object(rtk.Plane())
+    check_against_oracle(dev, oracle, scene, camera, "plane only")

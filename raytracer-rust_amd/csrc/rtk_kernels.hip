@@ -26,6 +26,12 @@
 
 #include <float.h>
 
+// The f64 code below restates the reference's arithmetic operation for operation.  rustc
+// never fuses a multiply with an add, so contraction stays off here as well: the exact
+// tests then take bit-identical decisions even in degenerate cases (tangent rays, points
+// lying on a surface).  The FP32 filter spells out its fused multiply-adds explicitly.
+#pragma clang fp contract(off)
+
 namespace rtk {
 
 // ------------------------------------------------------------------------------------

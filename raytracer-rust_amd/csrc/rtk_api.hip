@@ -8,6 +8,7 @@
 #include "rtk_device.h"
 #include "rtk_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -145,6 +146,8 @@ struct rtk_scene_handle {
   void* d_sph_object = nullptr;
   void* d_plane_object = nullptr;
   float4* d_prim = nullptr;  // primary-ray filter records (rebuilt per camera)
+  void* d_light_filter = nullptr;
+  void* d_k_table = nullptr;
 };
 
 struct rtk_context {
@@ -158,6 +161,9 @@ struct rtk_context {
   float* d_rgb = nullptr;
   uint8_t* d_rgba8 = nullptr;
   size_t cap_pixels = 0;
+  // intermediate records of the three-kernel path (grown on demand, kept for the next frame)
+  rtk::OpaqueBuffers opaque{};
+  size_t cap_opaque = 0;
 };
 
 extern "C" {
@@ -258,6 +264,9 @@ void rtk_destroy(rtk_context* ctx) {
   if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
   if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  if (ctx->opaque.hit_obj) (void)hipFree(ctx->opaque.hit_obj);
+  if (ctx->opaque.hit_t) (void)hipFree(ctx->opaque.hit_t);
+  if (ctx->opaque.shadow) (void)hipFree(ctx->opaque.shadow);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -267,7 +276,8 @@ void rtk_destroy(rtk_context* ctx) {
 void rtk_scene_release(rtk_context* ctx, rtk_scene_handle* h) {
   if (!h) return;
   if (ctx) (void)hipSetDevice(ctx->device);
-  void* ptrs[] = {h->d_objects, h->d_lights, h->d_filter, h->d_exact, h->d_sph_object, h->d_plane_object, h->d_prim};
+  void* ptrs[] = {h->d_objects, h->d_lights, h->d_filter, h->d_exact, h->d_sph_object, h->d_plane_object, h->d_prim,
+                  h->d_light_filter, h->d_k_table};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -366,6 +376,43 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
     c_max = std::fmax(c_max, round_up(std::sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]) * 1.0001));
   }
 
+  // Lights with w == 0 (what scene files produce, src/loader.rs:35-40): the shadow-ray line
+  // direction G = L.xyz does not depend on the shading point, so the per-(sphere, light)
+  // part of the filter, K = c.g - R'^2 rho, is tabulated here.
+  bool lights_uniform = scene->n_lights > 0;
+  std::vector<float4> light_filter(scene->n_lights);
+  std::vector<double> gd(4 * (size_t)scene->n_lights);
+  for (uint32_t k = 0; k < scene->n_lights; ++k) {
+    const double* L = scene->lights[k].position;
+    const double gg = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
+    if (L[3] != 0.0 || !(gg > 0.0) || !std::isfinite(gg)) {
+      lights_uniform = false;
+      light_filter[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    const double inv = 1.0 / std::sqrt(gg);
+    gd[4 * k + 0] = L[0] * inv;
+    gd[4 * k + 1] = L[1] * inv;
+    gd[4 * k + 2] = L[2] * inv;
+    gd[4 * k + 3] = -inv;  // rho = (w - 1)/|G|
+    light_filter[k] = make_float4((float)gd[4 * k], (float)gd[4 * k + 1], (float)gd[4 * k + 2], (float)gd[4 * k + 3]);
+  }
+  const uint32_t k_width = scene->n_lights <= 4 ? 4u : 8u;
+  std::vector<float> k_table;
+  if (lights_uniform && n_pad) {
+    const uint32_t batches = (scene->n_lights + k_width - 1) / k_width;
+    k_table.resize((size_t)batches * n_pad * k_width);
+    for (uint32_t b = 0; b < batches; ++b)
+      for (uint32_t j = 0; j < n_pad; ++j)
+        for (uint32_t e = 0; e < k_width; ++e) {
+          const uint32_t k = std::min(b * k_width + e, scene->n_lights - 1);  // pad a short batch with its last light
+          const float4 f = filter[j];
+          const double v = (double)f.x * gd[4 * k] + (double)f.y * gd[4 * k + 1] + (double)f.z * gd[4 * k + 2] -
+                           (double)f.w * gd[4 * k + 3];
+          k_table[((size_t)b * n_pad + j) * k_width + e] = (float)v;
+        }
+  }
+
   rtk_scene_handle* h = new (std::nothrow) rtk_scene_handle();
   if (!h) return fail(RTK_ERR_NOMEM, "rtk_scene_upload: out of host memory");
   hipError_t e = hipSetDevice(ctx->device);
@@ -380,6 +427,8 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   upload(&h->d_exact, sph_exact.data(), sph_exact.size() * sizeof(double4));
   upload(&h->d_sph_object, sph_object.data(), sph_object.size() * sizeof(uint32_t));
   upload(&h->d_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
+  upload(&h->d_light_filter, light_filter.data(), light_filter.size() * sizeof(float4));
+  upload(&h->d_k_table, k_table.data(), k_table.size() * sizeof(float));
   if (e == hipSuccess && n_pad) e = hipMalloc((void**)&h->d_prim, n_pad * sizeof(float4));
   if (e != hipSuccess) {
     rtk_scene_release(ctx, h);
@@ -392,6 +441,10 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   d.sph_exact = (const double4*)h->d_exact;
   d.sph_object = (const uint32_t*)h->d_sph_object;
   d.plane_object = (const uint32_t*)h->d_plane_object;
+  d.light_filter = (const float4*)h->d_light_filter;
+  d.k_table = (const float4*)h->d_k_table;
+  d.lights_uniform = lights_uniform ? 1u : 0u;
+  d.k_width = k_width;
   d.n_objects = scene->n_objects;
   d.n_lights = scene->n_lights;
   d.n_spheres = n_sph;
@@ -453,8 +506,27 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   RTK_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters), st));
   RTK_HIP(rtk::launch_prep_primary(st, scene->dev, cam, scene->d_prim));
+  const bool opaque = !scene->dev.any_secondary;
+  if (opaque) {
+    // intermediate hit / shadow records: one entry per pixel of this launch
+    const size_t need = (size_t)t.n_local_tiles * 256u;
+    if (need > ctx->cap_opaque) {
+      if (ctx->opaque.hit_obj) (void)hipFree(ctx->opaque.hit_obj);
+      if (ctx->opaque.hit_t) (void)hipFree(ctx->opaque.hit_t);
+      if (ctx->opaque.shadow) (void)hipFree(ctx->opaque.shadow);
+      ctx->opaque = rtk::OpaqueBuffers{};
+      ctx->cap_opaque = 0;
+      RTK_HIP(hipMalloc((void**)&ctx->opaque.hit_obj, need * sizeof(uint32_t)));
+      RTK_HIP(hipMalloc((void**)&ctx->opaque.hit_t, need * sizeof(double)));
+      RTK_HIP(hipMalloc((void**)&ctx->opaque.shadow, need));
+      ctx->cap_opaque = need;
+    }
+  }
   RTK_HIP(hipEventRecord(ctx->ev_start, st));
-  RTK_HIP(rtk::launch_render(st, scene->dev, cam, scene->d_prim, t, ctx->d_counters));
+  if (opaque)
+    RTK_HIP(rtk::launch_render_opaque(st, scene->dev, cam, scene->d_prim, t, ctx->opaque, ctx->d_counters));
+  else
+    RTK_HIP(rtk::launch_render(st, scene->dev, cam, scene->d_prim, t, ctx->d_counters));
   RTK_HIP(hipEventRecord(ctx->ev_stop, st));
   ctx->last_stream = st;
   ctx->have_timing = true;

@@ -51,10 +51,14 @@ struct DevScene {
   const double4* sph_exact;     // centre (world, f64) and bounding radius per filter record
   const uint32_t* sph_object;   // filter record -> object index
   const uint32_t* plane_object; // plane list -> object index
+  const float4* light_filter;   // per light: unit line direction g = G/|G| and rho = (w-1)/|G| for G = L.xyz (w = 0 lights)
+  const float4* k_table;        // [batch][sphere][k_width]: c_j.g_k - R_j'^2 rho_k, only when lights_uniform
   uint32_t n_objects, n_lights, n_spheres, n_spheres_padded, n_planes;
   uint32_t max_depth;
   uint32_t track_n1;     // some transparent object has refractivity != the others: keep n1
   uint32_t any_secondary; // some material reflects or transmits: rays recurse
+  uint32_t lights_uniform; // every light has w == 0: shadow-ray line directions do not depend on the shading point
+  uint32_t k_width;        // lights per k_table row (4 or 8)
   double center[3];      // recentring offset of the FP32 filter
   double ambient[3];
   float r2_max;          // max inflated squared radius
@@ -72,6 +76,14 @@ struct DevCamera {
 
 struct DevCounters {
   unsigned long long rays_primary, rays_shadow, rays_secondary, exact_tests;
+};
+
+// Intermediate records of the three-kernel path, one entry per pixel of the launch
+// (local tile k, slot s -> index k*256 + s).
+struct OpaqueBuffers {
+  uint32_t* hit_obj;  // object index of the closest hit, 0xffffffff = miss
+  double* hit_t;      // its ray parameter
+  uint8_t* shadow;    // bit 7: in shadow; bits 0..6: shadow rays the reference traces for this hit
 };
 
 struct RenderTarget {

@@ -16,6 +16,11 @@ hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamer
 hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim, const RenderTarget& T,
                          DevCounters* counters);
 
+// Same for scenes without reflective or transparent materials: three lean kernels
+// (camera rays, shadow rays, shading) with intermediate records in B.
+hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
+                                const RenderTarget& T, const OpaqueBuffers& B, DevCounters* counters);
+
 // Traces n caller-supplied rays (device pointers, n x 4 doubles in, n x 3 doubles out).
 hipError_t launch_trace_rays(hipStream_t st, const DevScene& S, const double* origins, const double* directions, uint64_t n,
                              double* colors, DevCounters* counters);

@@ -1,0 +1,491 @@
+// rtk_opaque.hip -- the render path for scenes without reflective or transparent
+// materials (every throughput configuration): three lean kernels instead of one.
+//
+//   primary_kernel   two pixels per lane; camera-ray sweep over all spheres (FP32 filter,
+//                    f64 on candidates), planes exact; writes the hit (object, t)
+//   shadow_*_kernel  rebuilds the shading point of each hit, sweeps all spheres for all
+//                    lights at once, writes the reference's shadow flag and ray count
+//   shade_kernel     rebuilds LightingData, samples the texture, sums Phong over the
+//                    lights and stores FP32 RGB + RGBA8 (transposed through LDS)
+//
+// Nothing of the f64 shading state is live across a sweep, so the sweep kernels fit in 64
+// VGPRs and run 8 wavefronts per SIMD.  The intermediate records (13 bytes per pixel) make
+// one round trip through HBM; that is noise next to the sweeps (tens of ms at 4K).
+//
+// Arithmetic of the decisions is unchanged from the single-kernel path (rtk_kernels.hip):
+// conservative FP32 filter, then the reference's own f64 formulas with contraction off.
+//
+// When every light of the scene has w = 0 (lights loaded from scene files,
+// src/loader.rs:35-40) the shadow ray's line direction g_k = L_k/|L_k| is the same for
+// every shading point, so the per-(sphere, light) part of the filter is tabulated at scene
+// upload: K[j][k] = c_j.g_k - R_j'^2 rho_k.  With P_k = p.g_k per lane,
+// h = u.g_k + R^2 rho_k = P_k - K[j][k]: two VALU instructions per (ray, sphere) plus a
+// seventh of the shared |p - c|^2 work.  Two pixels per lane keep the LDS reads (32 bytes
+// per sphere) below the VALU time.
+
+#include "rtk_shading.h"
+#include "rtk_sweeps.h"
+#include "rtk_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace rtk {
+
+constexpr int kShadowChunk = 512;  // records per LDS pass of the shadow kernels
+
+// Hides a value from the optimiser so that what is computed from it is recomputed where
+// it is used instead of being kept live across a sweep.
+__device__ __forceinline__ uint32_t launder(uint32_t v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+// Where a thread's pixel sits: local tile k (global tile k*world + rank), slot (lx, ly).
+struct PixelRef {
+  uint32_t x, y;   // frame coordinates
+  uint32_t local;  // index into the per-launch intermediate buffers
+  bool in_range;   // the tile exists
+  bool valid;      // ... and the pixel lies inside the frame
+};
+__device__ __forceinline__ PixelRef pixel_ref(const RenderTarget& T, const DevCamera& C, uint32_t k) {
+  PixelRef p;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t lx = (wave << 3) | (lane & 7u), ly = lane >> 3;
+  p.in_range = k < T.n_local_tiles;
+  const uint32_t tile = k * T.world + T.rank;
+  p.x = (tile % T.tiles_x) * 32u + lx;
+  p.y = (tile / T.tiles_x) * 8u + ly;
+  p.valid = p.in_range && p.x < C.width && p.y < C.height;
+  p.local = k * 256u + ly * 32u + lx;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------
+// Kernel 1: camera rays.  Workgroup b owns local tiles 2b' and 2b'+1 (bottom of the frame
+// first); each lane traces the same slot of both tiles.
+__global__ void __launch_bounds__(kBlock, 8) primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
+                                                           RenderTarget T, OpaqueBuffers B, DevCounters* counters) {
+  __shared__ float4 s_buf[kChunk];
+  const uint32_t pairs = (T.n_local_tiles + 1u) / 2u;
+  const uint32_t pr = pairs - 1u - blockIdx.x;
+  const PixelRef pa = pixel_ref(T, C, 2u * pr), pb = pixel_ref(T, C, 2u * pr + 1u);
+  const V3 origin = ld3(C.origin);
+
+  Closest best_a, best_b;
+  closest_init(best_a);
+  closest_init(best_b);
+  float ax, ay, az, bx, by, bz;
+  unsigned n_exact = 0;
+  {
+    const V3 da = camera_ray_direction(C, pa.x, pa.y), db = camera_ray_direction(C, pb.x, pb.y);
+    ax = (float)da.x, ay = (float)da.y, az = (float)da.z;
+    bx = (float)db.x, by = (float)db.y, bz = (float)db.z;
+    for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
+      const uint32_t obj = S.plane_object[ip];
+      double t0, t1;
+      if (pa.valid && intersect_object(S.objects[obj], origin, da, 0.0, t0, t1)) closest_consider(best_a, t0, obj, false);
+      if (pb.valid && intersect_object(S.objects[obj], origin, db, 0.0, t0, t1)) closest_consider(best_b, t0, obj, false);
+    }
+  }
+  const bool any_valid = pa.valid || pb.valid;
+  for (uint32_t base = 0; base < S.n_spheres_padded; base += kChunk) {
+    const uint32_t count = min((uint32_t)kChunk, S.n_spheres_padded - base);
+    stage_chunk(s_buf, prim, base, count);
+    if (!wave_any(any_valid)) continue;
+    for (uint32_t j = 0; j < count; j += kGroup) {
+      float4 q[kGroup];
+#pragma unroll
+      for (int g = 0; g < kGroup; ++g) q[g] = s_buf[j + g];
+      float m = -1.0f;
+#pragma unroll
+      for (int g = 0; g < kGroup; ++g) {
+        float ta = q[g].x * ax;
+        ta = __builtin_fmaf(q[g].y, ay, ta);
+        ta = __builtin_fmaf(q[g].z, az, ta);
+        float tb = q[g].x * bx;
+        tb = __builtin_fmaf(q[g].y, by, tb);
+        tb = __builtin_fmaf(q[g].z, bz, tb);
+        m = fmaxf(m, fmaxf(__builtin_fmaf(ta, ta, -q[g].w), __builtin_fmaf(tb, tb, -q[g].w)));
+      }
+      if (wave_any(m >= 0.0f)) {
+#pragma unroll 1
+        for (int g = 0; g < kGroup; ++g) {
+          const float4 r = s_buf[j + g];
+          float ta = r.x * ax;
+          ta = __builtin_fmaf(r.y, ay, ta);
+          ta = __builtin_fmaf(r.z, az, ta);
+          float tb = r.x * bx;
+          tb = __builtin_fmaf(r.y, by, tb);
+          tb = __builtin_fmaf(r.z, bz, tb);
+          const bool pass_a = pa.valid && __builtin_fmaf(ta, ta, -r.w) >= 0.0f;
+          const bool pass_b = pb.valid && __builtin_fmaf(tb, tb, -r.w) >= 0.0f;
+          if (wave_any(pass_a || pass_b)) {
+            const uint32_t obj = S.sph_object[base + j + g];
+            double t0, t1;
+            if (pass_a) {
+              ++n_exact;
+              const V3 d = camera_ray_direction(C, launder(pa.x), pa.y);
+              if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
+                closest_consider(best_a, t0, obj, false);
+                closest_consider(best_a, t1, obj, false);
+              }
+            }
+            if (pass_b) {
+              ++n_exact;
+              const V3 d = camera_ray_direction(C, launder(pb.x), pb.y);
+              if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
+                closest_consider(best_b, t0, obj, false);
+                closest_consider(best_b, t1, obj, false);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (pa.in_range) {
+    B.hit_obj[pa.local] = pa.valid ? best_a.obj : 0xffffffffu;
+    B.hit_t[pa.local] = best_a.t;
+  }
+  if (pb.in_range) {
+    B.hit_obj[pb.local] = pb.valid ? best_b.obj : 0xffffffffu;
+    B.hit_t[pb.local] = best_b.t;
+  }
+  unsigned n_primary = wave_sum((pa.valid ? 1u : 0u) + (pb.valid ? 1u : 0u));
+  n_exact = wave_sum(n_exact);
+  if ((threadIdx.x & 63u) == 0) {
+    atomicAdd(&counters->rays_primary, (unsigned long long)n_primary);
+    atomicAdd(&counters->exact_tests, (unsigned long long)n_exact);
+  }
+}
+
+// The shading point of a recorded hit: `over_position` of LightingData (src/scene/lighting.rs:50).
+__device__ __forceinline__ V3 over_point(const DevScene& S, const DevCamera& C, const PixelRef& p, uint32_t obj, double t) {
+  const V3 d = camera_ray_direction(C, p.x, p.y);
+  return lighting_data(S.objects[obj], ld3(C.origin), d, t).over;
+}
+
+// One shadow ray against one object, exactly: the per-light body of `Scene::is_shadowed`
+// (src/scene.rs:208-225).
+__device__ __forceinline__ bool shadow_ray_blocked(const DevObject& ob, const DevLight& L, V3 p) {
+  V3 lv = ld3(L.pos) - p;
+  const double lw = L.pos[3] - 1.0;
+  const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+  const V3 d = {lv.x / m, lv.y / m, lv.z / m};
+  double t0, t1;
+  const int n = intersect_object(ob, p, d, lw / m, t0, t1);
+  return (n >= 1 && t0 > 0.0 && t0 < m) || (n == 2 && t1 > 0.0 && t1 < m);
+}
+
+// Absolute filter slack for the tabulated form: on top of filter_threshold(), h = P - K is
+// a difference of two rounded numbers of size |p|, |c|: |dh| <= eps (6|p| + 2 c_max + 2B).
+__device__ __forceinline__ float filter_threshold_tabulated(const DevScene& S, V3 pc, float rho_max) {
+  const double pn = sqrt(dot3(pc, pc));
+  const double B = (double)S.r2_max * (double)rho_max;
+  const double dh = (double)kEps32 * (6.0 * pn + 2.0 * (double)S.c_max + 2.0 * B) * 1.01;
+  const double hmax = pn + (double)S.c_max + B;
+  const double extra = 2.0 * hmax * dh + dh * dh;
+  return filter_threshold(S, pc, rho_max) - (float)(extra * 1.001);
+}
+
+// ------------------------------------------------------------------------------------
+// Kernel 2a: shadow rays when every light has w = 0.  KW = lights per batch (4 or 8).
+template <int KW>
+__global__ void __launch_bounds__(kBlock, 6) shadow_uniform_kernel(DevScene S, DevCamera C, RenderTarget T, OpaqueBuffers B,
+                                                                  DevCounters* counters) {
+  constexpr int KV = KW / 4;             // float4 per table row
+  constexpr int kShadowGroup = 16 / KW;  // records per wavefront branch (32 ray-tests either way)
+  __shared__ float4 s_f[kShadowChunk];
+  __shared__ float4 s_k[kShadowChunk * KV];
+  const uint32_t pairs = (T.n_local_tiles + 1u) / 2u;
+  const uint32_t pr = pairs - 1u - blockIdx.x;
+  const PixelRef pa = pixel_ref(T, C, 2u * pr), pb = pixel_ref(T, C, 2u * pr + 1u);
+
+  uint32_t obj_a = 0xffffffffu, obj_b = 0xffffffffu;
+  if (pa.valid) obj_a = B.hit_obj[pa.local];
+  if (pb.valid) obj_b = B.hit_obj[pb.local];
+  bool need_a = obj_a != 0xffffffffu, need_b = obj_b != 0xffffffffu;
+  V3 p_a = {0, 0, 0}, p_b = {0, 0, 0};
+  if (need_a) p_a = over_point(S, C, pa, obj_a, B.hit_t[pa.local]);
+  if (need_b) p_b = over_point(S, C, pb, obj_b, B.hit_t[pb.local]);
+
+  unsigned rays_a = 0, rays_b = 0, n_exact = 0;
+  bool shadow_a = false, shadow_b = false;
+
+  for (uint32_t kb = 0, batch = 0; kb < S.n_lights; kb += KW, ++batch) {
+    if (!__syncthreads_or(need_a || need_b)) break;
+    const uint32_t nb = min((uint32_t)KW, S.n_lights - kb);
+    uint32_t occl_a = 0, occl_b = 0;
+    // planes: exact
+    for (uint32_t r = 0; r < nb; ++r)
+      for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
+        const DevObject& ob = S.objects[S.plane_object[ip]];
+        if (need_a && shadow_ray_blocked(ob, S.lights[kb + r], p_a)) occl_a |= 1u << r;
+        if (need_b && shadow_ray_blocked(ob, S.lights[kb + r], p_b)) occl_b |= 1u << r;
+      }
+    bool live_a = need_a && !(occl_a & 1u), live_b = need_b && !(occl_b & 1u);
+
+    // per-lane constants of the filter; a pixel that needs nothing is parked where no
+    // sphere can pass (|u|^2 ~ 3e30, h = -K)
+    float pax = 1.0e15f, pay = 1.0e15f, paz = 1.0e15f, pbx = 1.0e15f, pby = 1.0e15f, pbz = 1.0e15f;
+    float Pa[KW], Pb[KW];
+    float thr = 0.0f;
+    {
+      const V3 ca = {p_a.x - S.center[0], p_a.y - S.center[1], p_a.z - S.center[2]};
+      const V3 cb = {p_b.x - S.center[0], p_b.y - S.center[1], p_b.z - S.center[2]};
+      float rho_max = 0.0f;
+#pragma unroll
+      for (int k = 0; k < KW; ++k) rho_max = fmaxf(rho_max, fabsf(S.light_filter[kb + min((uint32_t)k, nb - 1u)].w) * 1.0001f);
+      if (live_a) {
+        pax = (float)ca.x, pay = (float)ca.y, paz = (float)ca.z;
+        thr = fminf(thr, filter_threshold_tabulated(S, ca, rho_max));
+      }
+      if (live_b) {
+        pbx = (float)cb.x, pby = (float)cb.y, pbz = (float)cb.z;
+        thr = fminf(thr, filter_threshold_tabulated(S, cb, rho_max));
+      }
+#pragma unroll
+      for (int k = 0; k < KW; ++k) {
+        const float4 lf = S.light_filter[kb + min((uint32_t)k, nb - 1u)];
+        Pa[k] = live_a ? __builtin_fmaf(paz, lf.z, __builtin_fmaf(pay, lf.y, pax * lf.x)) : 0.0f;
+        Pb[k] = live_b ? __builtin_fmaf(pbz, lf.z, __builtin_fmaf(pby, lf.y, pbx * lf.x)) : 0.0f;
+      }
+    }
+    const float4* __restrict__ ktab = S.k_table + (size_t)batch * S.n_spheres_padded * KV;
+
+    bool wave_live = wave_any(live_a || live_b);
+    for (uint32_t base = 0; base < S.n_spheres_padded; base += kShadowChunk) {
+      const uint32_t count = min((uint32_t)kShadowChunk, S.n_spheres_padded - base);
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < count; i += kBlock) s_f[i] = S.sph_filter[base + i];
+      for (uint32_t i = threadIdx.x; i < count * KV; i += kBlock) s_k[i] = ktab[(size_t)base * KV + i];
+      __syncthreads();
+      if (!wave_live) continue;
+      for (uint32_t j = 0; j < count; j += kShadowGroup) {
+        float4 q[kShadowGroup], kk[kShadowGroup][KV];
+#pragma unroll
+        for (int g = 0; g < kShadowGroup; ++g) {
+          q[g] = s_f[j + g];
+#pragma unroll
+          for (int v = 0; v < KV; ++v) kk[g][v] = s_k[(j + g) * KV + v];
+        }
+        float m = -3.0e38f;
+#pragma unroll
+        for (int g = 0; g < kShadowGroup; ++g) {
+          const float uxa = pax - q[g].x, uya = pay - q[g].y, uza = paz - q[g].z;
+          const float uxb = pbx - q[g].x, uyb = pby - q[g].y, uzb = pbz - q[g].z;
+          const float uua = __builtin_fmaf(uza, uza, __builtin_fmaf(uya, uya, uxa * uxa));
+          const float uub = __builtin_fmaf(uzb, uzb, __builtin_fmaf(uyb, uyb, uxb * uxb));
+          const float cfa = __builtin_fmaf(uua, kKappa, -q[g].w), cfb = __builtin_fmaf(uub, kKappa, -q[g].w);
+#pragma unroll
+          for (int k = 0; k < KW; ++k) {
+            const float kv = (&kk[g][k / 4].x)[k % 4];
+            const float ha = Pa[k] - kv, hb = Pb[k] - kv;
+            m = fmaxf(m, fmaxf(__builtin_fmaf(ha, ha, -cfa), __builtin_fmaf(hb, hb, -cfb)));
+          }
+        }
+        if (wave_any(m >= thr)) {
+#pragma unroll 1
+          for (int g = 0; g < kShadowGroup; ++g) {
+            const float4 c = s_f[j + g];
+            const float uxa = pax - c.x, uya = pay - c.y, uza = paz - c.z;
+            const float uxb = pbx - c.x, uyb = pby - c.y, uzb = pbz - c.z;
+            const float uua = __builtin_fmaf(uza, uza, __builtin_fmaf(uya, uya, uxa * uxa));
+            const float uub = __builtin_fmaf(uzb, uzb, __builtin_fmaf(uyb, uyb, uxb * uxb));
+            const float cfa = __builtin_fmaf(uua, kKappa, -c.w), cfb = __builtin_fmaf(uub, kKappa, -c.w);
+            uint32_t mask_a = 0, mask_b = 0;
+#pragma unroll
+            for (int v = 0; v < KV; ++v) {
+              const float4 row = s_k[(j + g) * KV + v];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int k = v * 4 + e;
+                const float kv = (&row.x)[e];
+                const float ha = Pa[k] - kv, hb = Pb[k] - kv;
+                if (__builtin_fmaf(ha, ha, -cfa) >= thr) mask_a |= 1u << k;
+                if (__builtin_fmaf(hb, hb, -cfb) >= thr) mask_b |= 1u << k;
+              }
+            }
+            if (!live_a) mask_a = 0;
+            if (!live_b) mask_b = 0;
+            mask_a &= ~occl_a;
+            mask_b &= ~occl_b;
+            if (wave_any((mask_a | mask_b) != 0)) {
+              const DevObject& ob = S.objects[S.sph_object[base + j + g]];
+              for (uint32_t r = 0; r < nb; ++r) {
+                if ((mask_a >> r) & 1u) {
+                  ++n_exact;
+                  if (shadow_ray_blocked(ob, S.lights[kb + r], p_a)) occl_a |= 1u << r;
+                }
+                if ((mask_b >> r) & 1u) {
+                  ++n_exact;
+                  if (shadow_ray_blocked(ob, S.lights[kb + r], p_b)) occl_b |= 1u << r;
+                }
+              }
+            }
+          }
+          // a pixel whose first light is blocked needs nothing more: park it
+          if (live_a && (occl_a & 1u)) {
+            live_a = false;
+            pax = pay = paz = 1.0e15f;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) Pa[k] = 0.0f;
+          }
+          if (live_b && (occl_b & 1u)) {
+            live_b = false;
+            pbx = pby = pbz = 1.0e15f;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) Pb[k] = 0.0f;
+          }
+          wave_live = wave_any(live_a || live_b);
+          if (!wave_live) break;
+        }
+      }
+    }
+    const uint32_t lights_mask = (nb >= 32u) ? 0xffffffffu : ((1u << nb) - 1u);
+    if (need_a) {
+      occl_a &= lights_mask;
+      if (occl_a) {
+        rays_a += (unsigned)__builtin_ctz(occl_a) + 1u;
+        shadow_a = true;
+        need_a = false;
+      } else {
+        rays_a += nb;
+      }
+    }
+    if (need_b) {
+      occl_b &= lights_mask;
+      if (occl_b) {
+        rays_b += (unsigned)__builtin_ctz(occl_b) + 1u;
+        shadow_b = true;
+        need_b = false;
+      } else {
+        rays_b += nb;
+      }
+    }
+  }
+  if (pa.in_range) B.shadow[pa.local] = (uint8_t)((shadow_a ? 0x80u : 0u) | rays_a);
+  if (pb.in_range) B.shadow[pb.local] = (uint8_t)((shadow_b ? 0x80u : 0u) | rays_b);
+  n_exact = wave_sum(n_exact);
+  if ((threadIdx.x & 63u) == 0) atomicAdd(&counters->exact_tests, (unsigned long long)n_exact);
+}
+
+
+// Kernel 2b: shadow rays for arbitrary lights (some w != 0): one pixel per lane, per-lane
+// line directions, LB lights fused.
+template <int LB>
+__global__ void __launch_bounds__(kBlock, 4) shadow_general_kernel(DevScene S, DevCamera C, RenderTarget T, OpaqueBuffers B,
+                                                                  DevCounters* counters) {
+  __shared__ float4 s_buf[kChunk];
+  const uint32_t k = T.n_local_tiles - 1u - blockIdx.x;
+  const PixelRef px = pixel_ref(T, C, k);
+  uint32_t obj = 0xffffffffu;
+  if (px.valid) obj = B.hit_obj[px.local];
+  const bool hit = obj != 0xffffffffu;
+  V3 p = {0, 0, 0};
+  if (hit) p = over_point(S, C, px, obj, B.hit_t[px.local]);
+  unsigned rays = 0, n_exact = 0;
+  const bool in_shadow = shadow_sweeps<LB>(S, s_buf, hit, p, rays, n_exact);
+  B.shadow[px.local] = (uint8_t)((in_shadow ? 0x80u : 0u) | rays);
+  n_exact = wave_sum(n_exact);
+  if ((threadIdx.x & 63u) == 0) atomicAdd(&counters->exact_tests, (unsigned long long)n_exact);
+}
+
+// ------------------------------------------------------------------------------------
+// Kernel 3: `apply_lighting` (src/scene.rs:172-205) for opaque materials and the store.
+__global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, RenderTarget T, OpaqueBuffers B,
+                                                      DevCounters* counters) {
+  __shared__ float s_rgb[768];
+  __shared__ uint32_t s_px[256];
+  const uint32_t k = blockIdx.x;
+  const PixelRef px = pixel_ref(T, C, k);
+  const V3 ambient = ld3(S.ambient);
+  V3 color = {0, 0, 0};
+  unsigned n_shadow = 0;
+  if (px.valid) {
+    color = ambient;  // a miss, or trace_inner at depth >= MAX_DEPTH, returns ambient_color
+    const uint32_t obj = B.hit_obj[px.local];
+    if (obj != 0xffffffffu) {
+      const uint8_t sh = B.shadow[px.local];
+      const bool in_shadow = (sh & 0x80u) != 0;
+      n_shadow = sh & 0x7fu;
+      const DevObject& ob = S.objects[obj];
+      const V3 d = camera_ray_direction(C, px.x, px.y);
+      const HitGeom g = lighting_data(ob, ld3(C.origin), d, B.hit_t[px.local]);
+      const V3 tex = sample_texture(ob, g.objp);
+      V3 surface = ambient;
+      for (uint32_t l = 0; l < S.n_lights; ++l)
+        surface = surface + phong_lighting(S.lights[l], ob, tex, g.over, g.eye, g.normal, in_shadow);
+      color = surface;  // the reflected and refracted parts are BLACK for these materials
+    }
+  }
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t lx = (wave << 3) | (lane & 7u), ly = lane >> 3;
+  const uint32_t slot = ly * 32u + lx;
+  s_rgb[slot * 3 + 0] = (float)color.x;
+  s_rgb[slot * 3 + 1] = (float)color.y;
+  s_rgb[slot * 3 + 2] = (float)color.z;
+  s_px[slot] = cast_u8(color.x) | (cast_u8(color.y) << 8) | (cast_u8(color.z) << 16) | 0xff000000u;
+  __syncthreads();
+  {
+    const uint32_t tile = k * T.world + T.rank;
+    const uint32_t tx = tile % T.tiles_x, ty = tile / T.tiles_x;
+    const uint32_t rx = threadIdx.x & 31u, ry = threadIdx.x >> 5;
+    const uint32_t gx = tx * 32u + rx, gy = ty * 8u + ry;
+    if (T.rgba8) {
+      uint32_t* out = reinterpret_cast<uint32_t*>(T.rgba8);
+      if (T.compact)
+        out[(size_t)k * 256u + threadIdx.x] = s_px[threadIdx.x];
+      else if (gx < C.width && gy < C.height)
+        out[(size_t)gx + (size_t)gy * C.width] = s_px[threadIdx.x];
+    }
+    if (T.rgb) {
+#pragma unroll
+      for (uint32_t pass = 0; pass < 3; ++pass) {
+        const uint32_t e = threadIdx.x + pass * 256u;
+        const uint32_t row = e / 96u, col = e % 96u;
+        if (T.compact) {
+          T.rgb[(size_t)k * 768u + e] = s_rgb[e];
+        } else {
+          const uint32_t fx = tx * 32u + col / 3u, fy = ty * 8u + row;
+          if (fx < C.width && fy < C.height) T.rgb[((size_t)fx + (size_t)fy * C.width) * 3u + col % 3u] = s_rgb[e];
+        }
+      }
+    }
+  }
+  n_shadow = wave_sum(n_shadow);
+  if (lane == 0) atomicAdd(&counters->rays_shadow, (unsigned long long)n_shadow);
+}
+
+// ------------------------------------------------------------------------------------
+hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
+                                const RenderTarget& T, const OpaqueBuffers& B, DevCounters* counters) {
+  if (T.n_local_tiles == 0) return hipSuccess;
+  const dim3 pairs((T.n_local_tiles + 1u) / 2u), tiles(T.n_local_tiles), block(kBlock);
+  if (S.max_depth > 0) {
+    hipLaunchKernelGGL(primary_kernel, pairs, block, 0, st, S, C, prim, T, B, counters);
+    if (S.lights_uniform) {
+      if (S.k_width == 4)
+        hipLaunchKernelGGL((shadow_uniform_kernel<4>), pairs, block, 0, st, S, C, T, B, counters);
+      else
+        hipLaunchKernelGGL((shadow_uniform_kernel<8>), pairs, block, 0, st, S, C, T, B, counters);
+    } else {
+      switch (light_batch_for(S.n_lights)) {
+        case 1: hipLaunchKernelGGL((shadow_general_kernel<1>), tiles, block, 0, st, S, C, T, B, counters); break;
+        case 2: hipLaunchKernelGGL((shadow_general_kernel<2>), tiles, block, 0, st, S, C, T, B, counters); break;
+        case 4: hipLaunchKernelGGL((shadow_general_kernel<4>), tiles, block, 0, st, S, C, T, B, counters); break;
+        default: hipLaunchKernelGGL((shadow_general_kernel<8>), tiles, block, 0, st, S, C, T, B, counters); break;
+      }
+    }
+  } else {
+    // MAX_DEPTH 0: trace_inner returns the ambient colour without intersecting anything
+    hipError_t e = hipMemsetAsync(B.hit_obj, 0xff, (size_t)T.n_local_tiles * 256u * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(shade_kernel, tiles, block, 0, st, S, C, T, B, counters);
+  return hipGetLastError();
+}
+
+}  // namespace rtk

@@ -1,0 +1,268 @@
+// rtk_shading.h -- device-side building blocks shared by the kernels: f64 vector helpers,
+// the exact object intersection, closest-hit bookkeeping, the reference's shading model,
+// and the set-up of the FP32 candidate filter.  Device code only (included by .hip files).
+#ifndef RTK_SHADING_H
+#define RTK_SHADING_H
+
+#include "rtk_device.h"
+
+#include <float.h>
+
+// The f64 code below restates the reference's arithmetic operation for operation.  rustc
+// never fuses a multiply with an add, so contraction stays off here as well: the exact
+// tests then take bit-identical decisions even in degenerate cases (tangent rays, points
+// lying on a surface).  The FP32 filter spells out its fused multiply-adds explicitly.
+#pragma clang fp contract(off)
+
+namespace rtk {
+
+// relative slack of the general filter: |u|^2 is scaled by this before R'^2 is subtracted
+constexpr float kKappa = 1.0f - 24.0f * kEps32;
+
+// ------------------------------------------------------------------------------------
+// small f64 vector helpers (xyz only; w is carried explicitly where the reference's
+// 4-component arithmetic makes it matter)
+struct V3 {
+  double x, y, z;
+};
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ double dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 ld3(const double* p) { return {p[0], p[1], p[2]}; }
+
+// rows 0..2 of an affine 4x4 times (v, w): the 4-term rows of src/maths/vectors.rs:205-223
+__device__ __forceinline__ V3 xform(const double* m, V3 v, double w) {
+  return {m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * w, m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7] * w,
+          m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * w};
+}
+
+// ------------------------------------------------------------------------------------
+// Exact f64 intersection of one object: `SceneNode::intersect` (src/scene.rs:75-84) with
+// `Sphere::intersect` (src/scene/shapes/spheres.rs:18-35) or `Plane::intersect`
+// (src/scene/shapes/planes.rs:22-28).  The ray origin has w = 1; dw is the direction's w
+// (0 for camera and secondary rays, non-zero for shadow rays towards a w != 1 light).
+__device__ __forceinline__ int intersect_object(const DevObject& ob, V3 o, V3 d, double dw, double& t0, double& t1) {
+  const double* m = ob.inv;
+  if (ob.kind == 1u) {
+    double oy = m[4] * o.x + m[5] * o.y + m[6] * o.z + m[7];
+    double dy = m[4] * d.x + m[5] * d.y + m[6] * d.z + m[7] * dw;
+    if (fabs(dy) < 0.00001) return 0;
+    t0 = -oy / dy;
+    return 1;
+  }
+  V3 oo = xform(m, o, 1.0);
+  V3 dd = xform(m, d, dw);
+  // direction.w stays dw (row 3 = 0 0 0 1) and takes part in `a`; sphere_to_ray.w = 1 - 1 = 0
+  double a = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z + dw * dw;
+  double b = 2.0 * (oo.x * dd.x + oo.y * dd.y + oo.z * dd.z);
+  double c = (oo.x * oo.x + oo.y * oo.y + oo.z * oo.z) - 1.0;
+  double disc = b * b - 4.0 * a * c;
+  if (disc >= 0.0) {
+    double s = sqrt(disc);
+    t0 = (-b - s) / (2.0 * a);
+    t1 = (-b + s) / (2.0 * a);
+    return 2;
+  }
+  return 0;
+}
+
+// Closest-hit bookkeeping.  The reference sorts all hits stably by distance and takes the
+// first strictly smallest positive one (src/scene.rs:164-166, 325-340): ties go to the
+// lowest object index.  `prev` is the entry just before the winner in that sorted list
+// (largest t <= 0, ties to the LAST in list order); its material gives n1
+// (src/scene/lighting.rs:81-116).
+struct Closest {
+  double t;
+  uint32_t obj;
+  double prev_t;
+  uint32_t prev_obj;
+};
+__device__ __forceinline__ void closest_init(Closest& c) {
+  c.t = DBL_MAX;
+  c.obj = 0xffffffffu;
+  c.prev_t = -DBL_MAX;
+  c.prev_obj = 0xffffffffu;
+}
+__device__ __forceinline__ void closest_consider(Closest& c, double t, uint32_t obj, bool track_prev) {
+  if (t > 0.0) {
+    if (t < c.t || (t == c.t && obj < c.obj)) {
+      c.t = t;
+      c.obj = obj;
+    }
+  } else if (track_prev && t <= 0.0) {
+    if (t > c.prev_t || (t == c.prev_t && obj >= c.prev_obj)) {
+      c.prev_t = t;
+      c.prev_obj = obj;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// LDS staging of one chunk of 16-byte filter records (all 256 threads take part).
+__device__ __forceinline__ void stage_chunk(float4* s_buf, const float4* __restrict__ src, uint32_t base, uint32_t count) {
+  __syncthreads();  // previous chunk fully consumed
+  for (uint32_t i = threadIdx.x; i < count; i += kBlock) s_buf[i] = src[base + i];
+  __syncthreads();
+}
+
+// Per-lane set-up of one filter ray.  For a light at L (w = L.w) seen from p the
+// reference's shadow ray has direction (L - p)/m with a w component (L.w - 1)/m that the
+// object's inverse transform turns into a per-object shift (src/scene.rs:208-225,
+// src/maths/rays.rs:31-41).  In the sphere's frame the ray runs along
+// G = L.xyz - L.w p through u = p - c, and a root exists only if
+// (u.G^ + R^2 rho)^2 >= |u|^2 - R^2 with G^ = G/|G|, rho = (L.w - 1)/|G|.
+// A plain ray (direction d, w = 0) is the case G = d, rho = 0.
+__device__ __forceinline__ void make_filter_ray(V3 G, double omega, float& gx, float& gy, float& gz, float& rho) {
+  double inv = 1.0 / sqrt(dot3(G, G));
+  gx = (float)(G.x * inv);
+  gy = (float)(G.y * inv);
+  gz = (float)(G.z * inv);
+  rho = (float)(omega * inv);
+}
+
+// Absolute slack of the filter for one lane: covers the FP32 rounding of the recentred
+// origin (treated as growing every bounding ball by dp), and the terms of the rounding
+// analysis that do not scale with |u|^2.  Returned as the (non-positive) threshold.
+__device__ __forceinline__ float filter_threshold(const DevScene& S, V3 pc, float rho_max) {
+  double pn = sqrt(dot3(pc, pc));
+  double dp = pn * (double)kEps32 * 1.0001;
+  double B = (double)S.r2_max * (double)rho_max;
+  double r2s = 2.0 * (double)S.r_max * dp + dp * dp;
+  double hmax = pn + (double)S.c_max + B;
+  double slack = r2s * (1.0 + 2.0 * hmax * (double)rho_max) + 64.0 * (double)kEps32 * (B * B + (double)S.r2_max);
+  return -(float)(slack * 1.001) - 1e-30f;
+}
+
+// ------------------------------------------------------------------------------------
+// Shading, all f64, following the reference line by line.
+
+// `Texture::sample_at` (src/scene/materials.rs:14-19) and the four patterns
+// (src/graphics/patterns.rs:57-65, 81-88, 105-116, 132-140).  Rust's `%` is fmod.
+__device__ __forceinline__ V3 sample_texture(const DevObject& ob, V3 p) {
+  V3 a = ld3(ob.color_a), b = ld3(ob.color_b);
+  switch (ob.texture_kind) {
+    case 1u:  // checker
+      return (fmod(floor(p.x) + floor(p.y) + floor(p.z), 2.0) == 0.0) ? a : b;
+    case 2u: {  // gradient
+      V3 distance = b - a;
+      double fraction = p.x - floor(p.x);
+      return a + distance * fraction;
+    }
+    case 3u: {  // ring
+      double x2 = p.x * p.x, z2 = p.z * p.z;
+      return (fmod(floor(sqrt(x2 + z2)), 2.0) == 0.0) ? a : b;
+    }
+    case 4u:  // striped
+      return (fmod(floor(p.x), 2.0) == 0.0) ? a : b;
+    default:
+      return a;
+  }
+}
+
+// `LightingData::calculate` (src/scene/lighting.rs:40-78) without the refractive indices.
+struct HitGeom {
+  V3 over, under, normal, eye, reflect, objp;
+};
+__device__ __forceinline__ HitGeom lighting_data(const DevObject& ob, V3 o, V3 d, double t) {
+  HitGeom h;
+  V3 world = o + d * t;
+  h.eye = -d;
+  V3 n;
+  if (ob.kind == 1u) {
+    n = ld3(ob.plane_normal);  // never transformed (src/scene/shapes/planes.rs:30-32)
+  } else {
+    // src/scene/shapes/spheres.rs:37-44: inverse^T * (object_point - origin), w := 0, normalize
+    V3 op = xform(ob.inv, world, 1.0);
+    const double* m = ob.inv;
+    n = {m[0] * op.x + m[4] * op.y + m[8] * op.z, m[1] * op.x + m[5] * op.y + m[9] * op.z,
+         m[2] * op.x + m[6] * op.y + m[10] * op.z};
+    double mag = sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+    n = {n.x / mag, n.y / mag, n.z / mag};
+  }
+  // offsets, texture point and reflection use the normal BEFORE the inside flip
+  h.over = world + n * 0.0001;
+  h.under = world - n * 0.0001;
+  h.objp = xform(ob.inv, h.over, 1.0);
+  h.reflect = d - (n * 2.0) * dot3(d, n);
+  if (dot3(n, h.eye) < 0.0) n = -n;
+  h.normal = n;
+  return h;
+}
+
+// `phong_lighting` (src/scene/lighting.rs:120-154) for one light; `tex` is the sampled
+// texture colour.  The light vector is normalised over four components: its w is
+// L.w - 1 (the shading point has w = 1).
+__device__ __forceinline__ V3 phong_lighting(const DevLight& L, const DevObject& ob, V3 tex, V3 over, V3 eye, V3 normal,
+                                             bool in_shadow) {
+  V3 intensity = ld3(L.intensity);
+  V3 effective = tex * intensity;
+  V3 ambient = effective * ob.ambient;
+  if (in_shadow) return ambient;
+  V3 lv = ld3(L.pos) - over;
+  double lw = L.pos[3] - 1.0;
+  double mag = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+  V3 ld = {lv.x / mag, lv.y / mag, lv.z / mag};
+  V3 diffuse = {0, 0, 0}, specular = {0, 0, 0};
+  double ldn = dot3(ld, normal);
+  if (ldn >= 0.0) {
+    diffuse = (effective * ob.diffuse) * ldn;
+    V3 rd = -(ld - (normal * 2.0) * ldn);
+    double rde = dot3(rd, eye);
+    if (rde >= 0.0) {
+      double factor = pow(rde, ob.shininess);
+      specular = (intensity * ob.specular) * factor;
+    }
+  }
+  return (ambient + diffuse) + specular;
+}
+
+// `Scene::shlick` (src/scene.rs:275-295); powi(5) by repeated squaring.
+__device__ __forceinline__ double shlick(double n1, double n2, double cosv) {
+  if (n1 > n2) {
+    double n = n1 / n2;
+    double sin_t2 = n * n * (1.0 - cosv * cosv);
+    if (sin_t2 > 1.0) return 1.0;
+    cosv = sqrt(1.0 - sin_t2);
+  }
+  double r0 = (n1 - n2) / (n1 + n2);
+  double r02 = r0 * r0;
+  double x = 1.0 - cosv;
+  double x2 = x * x;
+  return r02 + (1.0 - r02) * (x * (x2 * x2));
+}
+
+__device__ __forceinline__ bool is_approx_zero(double v) { return fabs(v) < 0.00001; }  // src/maths.rs:24-28
+
+// Rust's `as u8`: truncate toward zero, saturate, NaN -> 0 (src/graphics.rs:65-69)
+__device__ __forceinline__ uint32_t cast_u8(double c) {
+  double v = c * 255.0;
+  if (!(v > 0.0)) return 0u;
+  if (v >= 255.0) return 255u;
+  return (uint32_t)v;
+}
+
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+
+// `Camera::ray_for_pixel` (src/scene/cameras.rs:52-69) with the matrix inverse hoisted to
+// the host: the unit direction of the ray through pixel (x, y); the origin is C.origin.
+__device__ __forceinline__ V3 camera_ray_direction(const DevCamera& C, uint32_t x, uint32_t y) {
+  const double x_offset = ((double)x + 0.5) * C.pixel_size;
+  const double y_offset = ((double)y + 0.5) * C.pixel_size;
+  const double world_x = C.half_width - x_offset;
+  const double world_y = C.half_height - y_offset;
+  V3 pixel = xform(C.inv, V3{world_x, world_y, -1.0}, 1.0);
+  V3 dv = pixel - ld3(C.origin);
+  double mag = sqrt(dv.x * dv.x + dv.y * dv.y + dv.z * dv.z);
+  return {dv.x / mag, dv.y / mag, dv.z / mag};
+}
+
+}  // namespace rtk
+#endif

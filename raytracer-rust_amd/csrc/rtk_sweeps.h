@@ -1,0 +1,251 @@
+// rtk_sweeps.h -- the brute-force object sweeps with one ray (or one shading point) per
+// lane: camera rays, general rays, and the fused shadow rays with per-lane light
+// directions.  Device code only (included by .hip files after rtk_shading.h).
+#ifndef RTK_SWEEPS_H
+#define RTK_SWEEPS_H
+
+#include "rtk_shading.h"
+
+#pragma clang fp contract(off)
+
+namespace rtk {
+
+// ------------------------------------------------------------------------------------
+// Primary rays: all rays of a frame leave from the camera origin, so the per-sphere part
+// of the test is hoisted into the record {L = c - o, CC = |L|^2 (1 - slack) - R'^2}.
+// With a unit direction d the line can touch the bounding ball only if (L.d)^2 >= CC:
+// 3 multiply-adds, one fused square-and-subtract and a share of a max per test.
+template <typename ExactFn>
+__device__ __forceinline__ void sweep_primary(const DevScene& S, const float4* __restrict__ prim, float4* s_buf, bool active,
+                                              float dx, float dy, float dz, ExactFn&& exact) {
+  for (uint32_t base = 0; base < S.n_spheres_padded; base += kChunk) {
+    const uint32_t count = min((uint32_t)kChunk, S.n_spheres_padded - base);
+    stage_chunk(s_buf, prim, base, count);
+    if (!__any(active)) continue;  // wavefront has no live ray: only help with staging
+    for (uint32_t j = 0; j < count; j += kGroup) {
+      float4 q[kGroup];
+#pragma unroll
+      for (int g = 0; g < kGroup; ++g) q[g] = s_buf[j + g];
+      float m = -1.0f;
+#pragma unroll
+      for (int g = 0; g < kGroup; ++g) {
+        float t = q[g].x * dx;
+        t = __builtin_fmaf(q[g].y, dy, t);
+        t = __builtin_fmaf(q[g].z, dz, t);
+        m = fmaxf(m, __builtin_fmaf(t, t, -q[g].w));
+      }
+      if (__any(active && m >= 0.0f)) {
+        // leave the fast loop: find which of the eight records kept a candidate
+#pragma unroll 1
+        for (int g = 0; g < kGroup; ++g) {
+          float4 r = s_buf[j + g];
+          float t = r.x * dx;
+          t = __builtin_fmaf(r.y, dy, t);
+          t = __builtin_fmaf(r.z, dz, t);
+          bool pass = active && (__builtin_fmaf(t, t, -r.w) >= 0.0f);
+          if (__any(pass)) {
+            uint32_t obj = S.sph_object[base + j + g];
+            if (pass) exact(obj);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// General filter for NR rays that share the origin p (shadow rays of one shading point
+// towards NR lights, or a single secondary ray).  For a ray with unit line direction g
+// and "growth" rho (see make_filter_ray) a real intersection needs
+//     (u.g + R^2 rho)^2 - (|u|^2 - R^2) >= 0,   u = p - c.
+// The FP32 evaluation keeps a candidate when the computed value is >= thr (<= 0), where
+// kappa (relative, folded into the multiply-add) and thr (absolute, per lane) cover the
+// rounding of inputs and arithmetic.
+
+template <int NR, typename ExactFn, typename DoneFn>
+__device__ __forceinline__ void sweep_filter(const DevScene& S, float4* s_buf, bool& active, float px, float py, float pz,
+                                             const float (&gx)[NR], const float (&gy)[NR], const float (&gz)[NR],
+                                             const float (&rho)[NR], float thr, ExactFn&& exact, DoneFn&& done) {
+  bool wave_live = __any(active);
+  for (uint32_t base = 0; base < S.n_spheres_padded; base += kChunk) {
+    const uint32_t count = min((uint32_t)kChunk, S.n_spheres_padded - base);
+    stage_chunk(s_buf, S.sph_filter, base, count);
+    if (!wave_live) continue;
+    for (uint32_t j = 0; j < count; j += kGroup) {
+      float4 q[kGroup];
+#pragma unroll
+      for (int g = 0; g < kGroup; ++g) q[g] = s_buf[j + g];
+      float m = -3.0e38f;
+#pragma unroll
+      for (int g = 0; g < kGroup; ++g) {
+        float ux = px - q[g].x, uy = py - q[g].y, uz = pz - q[g].z;
+        float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+        float cf = __builtin_fmaf(uu, kKappa, -q[g].w);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          float h = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], __builtin_fmaf(ux, gx[r], q[g].w * rho[r])));
+          m = fmaxf(m, __builtin_fmaf(h, h, -cf));
+        }
+      }
+      if (__any(active && m >= thr)) {
+#pragma unroll 1
+        for (int g = 0; g < kGroup; ++g) {
+          float4 c = s_buf[j + g];
+          float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
+          float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+          float cf = __builtin_fmaf(uu, kKappa, -c.w);
+          uint32_t mask = 0;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            float h = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], __builtin_fmaf(ux, gx[r], c.w * rho[r])));
+            if (__builtin_fmaf(h, h, -cf) >= thr) mask |= 1u << r;
+          }
+          if (!active) mask = 0;
+          if (__any(mask != 0)) {
+            uint32_t obj = S.sph_object[base + j + g];
+            if (mask) exact(obj, mask);
+          }
+        }
+        // lanes that need no further test drop out; the wavefront stops once all have
+        if (active && done()) active = false;
+        wave_live = __any(active);
+        if (!wave_live) break;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Shadow test for one shading point: `Scene::is_shadowed` (src/scene.rs:208-225).
+// Lights are swept in batches of LB fused rays; the reference stops at the first blocked
+// light, so `n_rays` = index of the first blocked light + 1 (or the light count).
+template <int LB>
+__device__ __forceinline__ bool shadow_sweeps(const DevScene& S, float4* s_buf, bool active, V3 p, unsigned& n_rays,
+                                              unsigned& n_exact) {
+  bool in_shadow = false;
+  unsigned rays = 0;
+  bool need = active;
+  for (uint32_t kb = 0; kb < S.n_lights; kb += LB) {
+    if (!__syncthreads_or(need)) break;  // nobody in the tile still needs a light
+    const uint32_t nb = min((uint32_t)LB, S.n_lights - kb);
+    uint32_t occl = 0;
+    // planes: exact, per light (the shadow ray is rebuilt once per light)
+    if (need) {
+      for (uint32_t r = 0; r < nb; ++r) {
+        const DevLight& L = S.lights[kb + r];
+        V3 lv = ld3(L.pos) - p;
+        double lw = L.pos[3] - 1.0;
+        double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+        V3 d = {lv.x / m, lv.y / m, lv.z / m};
+        double dw = lw / m;
+        for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
+          double t0, t1;
+          int n = intersect_object(S.objects[S.plane_object[ip]], p, d, dw, t0, t1);
+          if (n >= 1 && t0 > 0.0 && t0 < m) occl |= 1u << r;
+        }
+      }
+    }
+    // spheres: fused FP32 filter, exact f64 on the candidates
+    float gx[LB], gy[LB], gz[LB], rho[LB];
+    float rho_max = 0.0f;
+    bool exotic = false;
+#pragma unroll
+    for (int r = 0; r < LB; ++r) {
+      const DevLight& L = S.lights[kb + min((uint32_t)r, nb - 1)];  // pad with the last real light
+      double lw = L.pos[3];
+      V3 G = ld3(L.pos) - p * lw;
+      make_filter_ray(G, lw - 1.0, gx[r], gy[r], gz[r], rho[r]);
+      rho_max = fmaxf(rho_max, fabsf(rho[r]) * 1.0001f);
+      exotic |= !(lw >= 0.0 && lw <= 1.0) || !(dot3(G, G) > 0.0);  // the line form needs 1 + (w-1) t > 0 and G != 0
+    }
+    V3 pc = {p.x - S.center[0], p.y - S.center[1], p.z - S.center[2]};
+    float thr = exotic ? -3.0e38f : filter_threshold(S, pc, rho_max);
+    bool live = need && !(occl & 1u);
+    auto exact = [&](uint32_t obj, uint32_t mask) {
+      const DevObject& ob = S.objects[obj];
+      for (uint32_t r = 0; r < nb; ++r) {
+        if (!((mask >> r) & 1u) || ((occl >> r) & 1u)) continue;
+        const DevLight& L = S.lights[kb + r];
+        V3 lv = ld3(L.pos) - p;
+        double lw = L.pos[3] - 1.0;
+        double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+        V3 d = {lv.x / m, lv.y / m, lv.z / m};
+        double t0, t1;
+        int n = intersect_object(ob, p, d, lw / m, t0, t1);
+        ++n_exact;
+        if (n == 2 && ((t0 > 0.0 && t0 < m) || (t1 > 0.0 && t1 < m))) occl |= 1u << r;
+      }
+    };
+    auto done = [&]() { return (occl & 1u) != 0; };
+    sweep_filter<LB>(S, s_buf, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done);
+    if (need) {
+      occl &= (1u << nb) - 1u;
+      if (occl) {
+        rays += (unsigned)__builtin_ctz(occl) + 1u;
+        in_shadow = true;
+        need = false;
+      } else {
+        rays += nb;
+      }
+    }
+  }
+  n_rays += rays;
+  return in_shadow;
+}
+
+// ------------------------------------------------------------------------------------
+// Closest hit of a general ray (origin o, direction d with w = 0, not necessarily unit):
+// `Scene::intersect` + `HitList::closest_hit` (src/scene.rs:156-169, 325-340).
+__device__ __forceinline__ void closest_general(const DevScene& S, float4* s_buf, bool active, V3 o, V3 d, Closest& best,
+                                                unsigned& n_exact) {
+  closest_init(best);
+  const bool track = S.track_n1 != 0;
+  if (active) {
+    for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
+      uint32_t obj = S.plane_object[ip];
+      double t0, t1;
+      if (intersect_object(S.objects[obj], o, d, 0.0, t0, t1)) closest_consider(best, t0, obj, track);
+    }
+  }
+  float gx[1], gy[1], gz[1], rho[1];
+  make_filter_ray(d, 0.0, gx[0], gy[0], gz[0], rho[0]);
+  V3 pc = {o.x - S.center[0], o.y - S.center[1], o.z - S.center[2]};
+  float thr = filter_threshold(S, pc, 0.0f);
+  auto exact = [&](uint32_t obj, uint32_t) {
+    double t0, t1;
+    ++n_exact;
+    if (intersect_object(S.objects[obj], o, d, 0.0, t0, t1)) {
+      closest_consider(best, t0, obj, track);
+      closest_consider(best, t1, obj, track);
+    }
+  };
+  auto done = [&]() { return false; };
+  bool live = active;
+  sweep_filter<1>(S, s_buf, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done);
+}
+
+// Closest hit of a camera ray (unit direction, shared origin).
+__device__ __forceinline__ void closest_primary(const DevScene& S, const float4* __restrict__ prim, float4* s_buf, bool active,
+                                                V3 o, V3 d, Closest& best, unsigned& n_exact) {
+  closest_init(best);
+  const bool track = S.track_n1 != 0;
+  if (active) {
+    for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
+      uint32_t obj = S.plane_object[ip];
+      double t0, t1;
+      if (intersect_object(S.objects[obj], o, d, 0.0, t0, t1)) closest_consider(best, t0, obj, track);
+    }
+  }
+  auto exact = [&](uint32_t obj) {
+    double t0, t1;
+    ++n_exact;
+    if (intersect_object(S.objects[obj], o, d, 0.0, t0, t1)) {
+      closest_consider(best, t0, obj, track);
+      closest_consider(best, t1, obj, track);
+    }
+  };
+  sweep_primary(S, prim, s_buf, active, (float)d.x, (float)d.y, (float)d.z, exact);
+}
+
+}  // namespace rtk
+#endif

@@ -1,0 +1,28 @@
+"""Kernel-time-only micro bench: best-of-N HIP-event time of the render kernel per config."""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+rtk = importlib.import_module("raytracer-rust_amd")
+device = importlib.import_module("raytracer-rust_amd.device")
+dev = device.Device(0)
+names = sys.argv[1:] or ["C2", "C3", "C4"]
+for name in names:
+    if name == "C1":
+        scene = rtk.PackedScene.from_yaml_file(os.path.join(ROOT, "tests/golden/test01.yaml")).build()
+        camera = rtk.Camera(1920, 1080, rtk.PI / 3)
+    elif name == "C5s":
+        scene, camera = rtk.synthetic.config("C5", 4096, 4096)
+    else:
+        scene, camera = rtk.synthetic.config(name)
+    h = dev.upload(scene)
+    best = None
+    for _ in range(6):
+        dev.render_device(h, camera)
+        st = dev.stats()
+        if best is None or st.kernel_ms < best.kernel_ms:
+            best = st
+    nsph = sum(1 for n in scene.nodes if n.kind == 0)
+    fl = 26 * nsph + 8 * (len(scene.nodes) - nsph)
+    print(f"{name}: {best.kernel_ms:8.3f} ms  {best.rays / best.kernel_ms / 1e3:9.1f} Mrays/s  "
+          f"{100 * best.rays * fl / (best.kernel_ms * 1e-3) / 157.3e12:6.1f}% of FP32 peak (algorithmic)  exact/ray-test {best.exact_tests / (best.rays * max(nsph,1)):.2e}", flush=True)
+    h.release()

@@ -148,6 +148,7 @@ struct rtk_scene_handle {
   float4* d_prim = nullptr;  // primary-ray filter records (rebuilt per camera)
   void* d_light_filter = nullptr;
   void* d_k_table = nullptr;
+  void* d_sph_tab = nullptr;
 };
 
 struct rtk_context {
@@ -267,6 +268,7 @@ void rtk_destroy(rtk_context* ctx) {
   if (ctx->opaque.hit_obj) (void)hipFree(ctx->opaque.hit_obj);
   if (ctx->opaque.hit_t) (void)hipFree(ctx->opaque.hit_t);
   if (ctx->opaque.shadow) (void)hipFree(ctx->opaque.shadow);
+  if (ctx->opaque.over) (void)hipFree(ctx->opaque.over);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -277,7 +279,7 @@ void rtk_scene_release(rtk_context* ctx, rtk_scene_handle* h) {
   if (!h) return;
   if (ctx) (void)hipSetDevice(ctx->device);
   void* ptrs[] = {h->d_objects, h->d_lights, h->d_filter, h->d_exact, h->d_sph_object, h->d_plane_object, h->d_prim,
-                  h->d_light_filter, h->d_k_table};
+                  h->d_light_filter, h->d_k_table, h->d_sph_tab};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -399,7 +401,17 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   }
   const uint32_t k_width = scene->n_lights <= 4 ? 4u : 8u;
   std::vector<float> k_table;
+  std::vector<float4> sph_tab;
   if (lights_uniform && n_pad) {
+    sph_tab.resize(n_pad);
+    const double kappa = (double)(1.0f - 24.0f * rtk::kEps32);
+    for (uint32_t j = 0; j < n_pad; ++j) {
+      const float4 f = filter[j];
+      const double cc = kappa * ((double)f.x * f.x + (double)f.y * f.y + (double)f.z * f.z) - (double)f.w;
+      float ccf = (float)cc;
+      if ((double)ccf > cc) ccf = std::nextafterf(ccf, -INFINITY);
+      sph_tab[j] = make_float4(f.x, f.y, f.z, std::nextafterf(ccf, -INFINITY));
+    }
     const uint32_t batches = (scene->n_lights + k_width - 1) / k_width;
     k_table.resize((size_t)batches * n_pad * k_width);
     for (uint32_t b = 0; b < batches; ++b)
@@ -429,6 +441,7 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   upload(&h->d_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
   upload(&h->d_light_filter, light_filter.data(), light_filter.size() * sizeof(float4));
   upload(&h->d_k_table, k_table.data(), k_table.size() * sizeof(float));
+  upload(&h->d_sph_tab, sph_tab.data(), sph_tab.size() * sizeof(float4));
   if (e == hipSuccess && n_pad) e = hipMalloc((void**)&h->d_prim, n_pad * sizeof(float4));
   if (e != hipSuccess) {
     rtk_scene_release(ctx, h);
@@ -443,6 +456,7 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   d.plane_object = (const uint32_t*)h->d_plane_object;
   d.light_filter = (const float4*)h->d_light_filter;
   d.k_table = (const float4*)h->d_k_table;
+  d.sph_tab = (const float4*)h->d_sph_tab;
   d.lights_uniform = lights_uniform ? 1u : 0u;
   d.k_width = k_width;
   d.n_objects = scene->n_objects;
@@ -514,11 +528,13 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
       if (ctx->opaque.hit_obj) (void)hipFree(ctx->opaque.hit_obj);
       if (ctx->opaque.hit_t) (void)hipFree(ctx->opaque.hit_t);
       if (ctx->opaque.shadow) (void)hipFree(ctx->opaque.shadow);
+      if (ctx->opaque.over) (void)hipFree(ctx->opaque.over);
       ctx->opaque = rtk::OpaqueBuffers{};
       ctx->cap_opaque = 0;
       RTK_HIP(hipMalloc((void**)&ctx->opaque.hit_obj, need * sizeof(uint32_t)));
       RTK_HIP(hipMalloc((void**)&ctx->opaque.hit_t, need * sizeof(double)));
       RTK_HIP(hipMalloc((void**)&ctx->opaque.shadow, need));
+      RTK_HIP(hipMalloc((void**)&ctx->opaque.over, need * 3 * sizeof(double)));
       ctx->cap_opaque = need;
     }
   }

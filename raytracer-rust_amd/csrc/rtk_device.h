@@ -53,6 +53,7 @@ struct DevScene {
   const uint32_t* plane_object; // plane list -> object index
   const float4* light_filter;   // per light: unit line direction g = G/|G| and rho = (w-1)/|G| for G = L.xyz (w = 0 lights)
   const float4* k_table;        // [batch][sphere][k_width]: c_j.g_k - R_j'^2 rho_k, only when lights_uniform
+  const float4* sph_tab;        // {cx, cy, cz, kappa |c|^2 - R'^2}: sphere record of the tabulated shadow filter
   uint32_t n_objects, n_lights, n_spheres, n_spheres_padded, n_planes;
   uint32_t max_depth;
   uint32_t track_n1;     // some transparent object has refractivity != the others: keep n1
@@ -84,6 +85,7 @@ struct OpaqueBuffers {
   uint32_t* hit_obj;  // object index of the closest hit, 0xffffffff = miss
   double* hit_t;      // its ray parameter
   uint8_t* shadow;    // bit 7: in shadow; bits 0..6: shadow rays the reference traces for this hit
+  double* over;       // shading point (x | y | z planes of n entries each), read back by the exact shadow tests
 };
 
 struct RenderTarget {

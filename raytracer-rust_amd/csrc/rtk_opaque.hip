@@ -179,21 +179,60 @@ __device__ __forceinline__ bool shadow_ray_blocked(const DevObject& ob, const De
   return (n >= 1 && t0 > 0.0 && t0 < m) || (n == 2 && t1 > 0.0 && t1 < m);
 }
 
-// Absolute filter slack for the tabulated form: on top of filter_threshold(), h = P - K is
-// a difference of two rounded numbers of size |p|, |c|: |dh| <= eps (6|p| + 2 c_max + 2B).
-__device__ __forceinline__ float filter_threshold_tabulated(const DevScene& S, V3 pc, float rho_max) {
-  const double pn = sqrt(dot3(pc, pc));
+// The tabulated filter of one pixel.  With the recentred, FP32-rounded shading point p,
+// per light P_k = p.g_k, and per sphere the record {c, CC = kappa |c|^2 - R'^2} and the row
+// K_k = c.g_k - R'^2 rho_k, the general test  (u.g_k + R'^2 rho_k)^2 - (kappa |u|^2 - R'^2) >= thr
+// becomes
+//     (P_k - K_k)^2 + (2 kappa p.c - CC) >= thr + kappa |p|^2  (= thrp),
+// i.e. 4 VALU instructions per (pixel, sphere) plus 2 per (pixel, sphere, light).  |p|^2 and
+// |c|^2 now cancel in FP32; the absolute slack in thr pays for that.
+template <int KW>
+struct PixelFilter {
+  float x, y, z;  // recentred shading point; (0,0,0) when parked
+  float P[KW];    // p.g_k
+  float thrp;     // threshold; +3e38 when parked (nothing passes)
+};
+template <int KW>
+__device__ __forceinline__ void park(PixelFilter<KW>& f) {
+  f.x = f.y = f.z = 0.0f;
+#pragma unroll
+  for (int k = 0; k < KW; ++k) f.P[k] = 0.0f;
+  f.thrp = 3.0e38f;
+}
+template <int KW>
+__device__ __forceinline__ void arm(PixelFilter<KW>& f, const DevScene& S, V3 p, uint32_t kb, uint32_t nb) {
+  const V3 pc = {p.x - S.center[0], p.y - S.center[1], p.z - S.center[2]};
+  f.x = (float)pc.x, f.y = (float)pc.y, f.z = (float)pc.z;
+  float rho_max = 0.0f;
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    const float4 lf = S.light_filter[kb + min((uint32_t)k, nb - 1u)];  // a short batch repeats its last light
+    f.P[k] = __builtin_fmaf(f.z, lf.z, __builtin_fmaf(f.y, lf.y, f.x * lf.x));
+    rho_max = fmaxf(rho_max, fabsf(lf.w) * 1.0001f);
+  }
+  // slack: everything filter_threshold() covers, plus
+  //  - h = P - K, a difference of rounded numbers: |dh| <= eps (6|p| + 2 c_max + 2B)
+  //  - the expanded |u|^2: roundings of p.c, CC and the two fused multiply-adds,
+  //    <= eps (5|p|^2 + 6 c_max^2 + 2 R_max^2)
+  const double pn2 = dot3(pc, pc), pn = sqrt(pn2);
   const double B = (double)S.r2_max * (double)rho_max;
   const double dh = (double)kEps32 * (6.0 * pn + 2.0 * (double)S.c_max + 2.0 * B) * 1.01;
   const double hmax = pn + (double)S.c_max + B;
-  const double extra = 2.0 * hmax * dh + dh * dh;
-  return filter_threshold(S, pc, rho_max) - (float)(extra * 1.001);
+  const double cm2 = (double)S.c_max * (double)S.c_max;
+  const double extra = 2.0 * hmax * dh + dh * dh + 6.0 * (double)kEps32 * (pn2 + cm2 + (double)S.r2_max) * 1.01;
+  const double thr = (double)filter_threshold(S, pc, rho_max) - extra * 1.001;
+  const double pp = (double)f.x * f.x + (double)f.y * f.y + (double)f.z * f.z;
+  const double t = (double)kKappa * pp + thr;
+  float tf = (float)t;
+  if ((double)tf > t) tf = nextafterf(tf, -INFINITY);
+  f.thrp = nextafterf(tf, -INFINITY);
 }
+constexpr float kTwoKappa = 2.0f * kKappa;
 
 // ------------------------------------------------------------------------------------
 // Kernel 2a: shadow rays when every light has w = 0.  KW = lights per batch (4 or 8).
 template <int KW>
-__global__ void __launch_bounds__(kBlock, 6) shadow_uniform_kernel(DevScene S, DevCamera C, RenderTarget T, OpaqueBuffers B,
+__global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel(DevScene S, DevCamera C, RenderTarget T, OpaqueBuffers B,
                                                                   DevCounters* counters) {
   constexpr int KV = KW / 4;             // float4 per table row
   constexpr int kShadowGroup = 16 / KW;  // records per wavefront branch (32 ray-tests either way)
@@ -207,9 +246,21 @@ __global__ void __launch_bounds__(kBlock, 6) shadow_uniform_kernel(DevScene S, D
   if (pa.valid) obj_a = B.hit_obj[pa.local];
   if (pb.valid) obj_b = B.hit_obj[pb.local];
   bool need_a = obj_a != 0xffffffffu, need_b = obj_b != 0xffffffffu;
-  V3 p_a = {0, 0, 0}, p_b = {0, 0, 0};
-  if (need_a) p_a = over_point(S, C, pa, obj_a, B.hit_t[pa.local]);
-  if (need_b) p_b = over_point(S, C, pb, obj_b, B.hit_t[pb.local]);
+  // The f64 shading points are needed only by the exact tests; they are parked in HBM and
+  // re-read there so that they do not occupy 12 VGPRs across the sweep.
+  const size_t stride = (size_t)T.n_local_tiles * 256u;
+  if (need_a) {
+    const V3 p = over_point(S, C, pa, obj_a, B.hit_t[pa.local]);
+    B.over[pa.local] = p.x, B.over[stride + pa.local] = p.y, B.over[2 * stride + pa.local] = p.z;
+  }
+  if (need_b) {
+    const V3 p = over_point(S, C, pb, obj_b, B.hit_t[pb.local]);
+    B.over[pb.local] = p.x, B.over[stride + pb.local] = p.y, B.over[2 * stride + pb.local] = p.z;
+  }
+  auto load_p = [&](const PixelRef& px) {
+    const uint32_t i = launder(px.local);
+    return V3{B.over[i], B.over[stride + i], B.over[2 * stride + i]};
+  };
 
   unsigned rays_a = 0, rays_b = 0, n_exact = 0;
   bool shadow_a = false, shadow_b = false;
@@ -219,39 +270,25 @@ __global__ void __launch_bounds__(kBlock, 6) shadow_uniform_kernel(DevScene S, D
     const uint32_t nb = min((uint32_t)KW, S.n_lights - kb);
     uint32_t occl_a = 0, occl_b = 0;
     // planes: exact
-    for (uint32_t r = 0; r < nb; ++r)
-      for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
-        const DevObject& ob = S.objects[S.plane_object[ip]];
-        if (need_a && shadow_ray_blocked(ob, S.lights[kb + r], p_a)) occl_a |= 1u << r;
-        if (need_b && shadow_ray_blocked(ob, S.lights[kb + r], p_b)) occl_b |= 1u << r;
-      }
-    bool live_a = need_a && !(occl_a & 1u), live_b = need_b && !(occl_b & 1u);
-
-    // per-lane constants of the filter; a pixel that needs nothing is parked where no
-    // sphere can pass (|u|^2 ~ 3e30, h = -K)
-    float pax = 1.0e15f, pay = 1.0e15f, paz = 1.0e15f, pbx = 1.0e15f, pby = 1.0e15f, pbz = 1.0e15f;
-    float Pa[KW], Pb[KW];
-    float thr = 0.0f;
-    {
-      const V3 ca = {p_a.x - S.center[0], p_a.y - S.center[1], p_a.z - S.center[2]};
-      const V3 cb = {p_b.x - S.center[0], p_b.y - S.center[1], p_b.z - S.center[2]};
-      float rho_max = 0.0f;
-#pragma unroll
-      for (int k = 0; k < KW; ++k) rho_max = fmaxf(rho_max, fabsf(S.light_filter[kb + min((uint32_t)k, nb - 1u)].w) * 1.0001f);
-      if (live_a) {
-        pax = (float)ca.x, pay = (float)ca.y, paz = (float)ca.z;
-        thr = fminf(thr, filter_threshold_tabulated(S, ca, rho_max));
-      }
-      if (live_b) {
-        pbx = (float)cb.x, pby = (float)cb.y, pbz = (float)cb.z;
-        thr = fminf(thr, filter_threshold_tabulated(S, cb, rho_max));
-      }
-#pragma unroll
-      for (int k = 0; k < KW; ++k) {
-        const float4 lf = S.light_filter[kb + min((uint32_t)k, nb - 1u)];
-        Pa[k] = live_a ? __builtin_fmaf(paz, lf.z, __builtin_fmaf(pay, lf.y, pax * lf.x)) : 0.0f;
-        Pb[k] = live_b ? __builtin_fmaf(pbz, lf.z, __builtin_fmaf(pby, lf.y, pbx * lf.x)) : 0.0f;
-      }
+    PixelFilter<KW> fa, fb;
+    park(fa);
+    park(fb);
+    bool live_a = false, live_b = false;
+    if (need_a) {
+      const V3 p = load_p(pa);
+      for (uint32_t r = 0; r < nb; ++r)
+        for (uint32_t ip = 0; ip < S.n_planes; ++ip)
+          if (shadow_ray_blocked(S.objects[S.plane_object[ip]], S.lights[kb + r], p)) occl_a |= 1u << r;
+      live_a = !(occl_a & 1u);
+      if (live_a) arm(fa, S, p, kb, nb);
+    }
+    if (need_b) {
+      const V3 p = load_p(pb);
+      for (uint32_t r = 0; r < nb; ++r)
+        for (uint32_t ip = 0; ip < S.n_planes; ++ip)
+          if (shadow_ray_blocked(S.objects[S.plane_object[ip]], S.lights[kb + r], p)) occl_b |= 1u << r;
+      live_b = !(occl_b & 1u);
+      if (live_b) arm(fb, S, p, kb, nb);
     }
     const float4* __restrict__ ktab = S.k_table + (size_t)batch * S.n_spheres_padded * KV;
 
@@ -259,7 +296,7 @@ __global__ void __launch_bounds__(kBlock, 6) shadow_uniform_kernel(DevScene S, D
     for (uint32_t base = 0; base < S.n_spheres_padded; base += kShadowChunk) {
       const uint32_t count = min((uint32_t)kShadowChunk, S.n_spheres_padded - base);
       __syncthreads();
-      for (uint32_t i = threadIdx.x; i < count; i += kBlock) s_f[i] = S.sph_filter[base + i];
+      for (uint32_t i = threadIdx.x; i < count; i += kBlock) s_f[i] = S.sph_tab[base + i];
       for (uint32_t i = threadIdx.x; i < count * KV; i += kBlock) s_k[i] = ktab[(size_t)base * KV + i];
       __syncthreads();
       if (!wave_live) continue;
@@ -271,30 +308,28 @@ __global__ void __launch_bounds__(kBlock, 6) shadow_uniform_kernel(DevScene S, D
 #pragma unroll
           for (int v = 0; v < KV; ++v) kk[g][v] = s_k[(j + g) * KV + v];
         }
-        float m = -3.0e38f;
+        float ma = -3.0e38f, mb = -3.0e38f;
 #pragma unroll
         for (int g = 0; g < kShadowGroup; ++g) {
-          const float uxa = pax - q[g].x, uya = pay - q[g].y, uza = paz - q[g].z;
-          const float uxb = pbx - q[g].x, uyb = pby - q[g].y, uzb = pbz - q[g].z;
-          const float uua = __builtin_fmaf(uza, uza, __builtin_fmaf(uya, uya, uxa * uxa));
-          const float uub = __builtin_fmaf(uzb, uzb, __builtin_fmaf(uyb, uyb, uxb * uxb));
-          const float cfa = __builtin_fmaf(uua, kKappa, -q[g].w), cfb = __builtin_fmaf(uub, kKappa, -q[g].w);
+          const float pca = __builtin_fmaf(fa.z, q[g].z, __builtin_fmaf(fa.y, q[g].y, fa.x * q[g].x));
+          const float pcb = __builtin_fmaf(fb.z, q[g].z, __builtin_fmaf(fb.y, q[g].y, fb.x * q[g].x));
+          const float ea = __builtin_fmaf(pca, kTwoKappa, -q[g].w), eb = __builtin_fmaf(pcb, kTwoKappa, -q[g].w);
 #pragma unroll
-          for (int k = 0; k < KW; ++k) {
-            const float kv = (&kk[g][k / 4].x)[k % 4];
-            const float ha = Pa[k] - kv, hb = Pb[k] - kv;
-            m = fmaxf(m, fmaxf(__builtin_fmaf(ha, ha, -cfa), __builtin_fmaf(hb, hb, -cfb)));
+          for (int k = 0; k < KW; k += 2) {
+            const float k0 = (&kk[g][k / 4].x)[k % 4], k1 = (&kk[g][(k + 1) / 4].x)[(k + 1) % 4];
+            const float ha0 = fa.P[k] - k0, ha1 = fa.P[k + 1] - k1;
+            const float hb0 = fb.P[k] - k0, hb1 = fb.P[k + 1] - k1;
+            ma = fmaxf(fmaxf(ma, __builtin_fmaf(ha0, ha0, ea)), __builtin_fmaf(ha1, ha1, ea));
+            mb = fmaxf(fmaxf(mb, __builtin_fmaf(hb0, hb0, eb)), __builtin_fmaf(hb1, hb1, eb));
           }
         }
-        if (wave_any(m >= thr)) {
+        if (wave_any(ma >= fa.thrp || mb >= fb.thrp)) {
 #pragma unroll 1
           for (int g = 0; g < kShadowGroup; ++g) {
             const float4 c = s_f[j + g];
-            const float uxa = pax - c.x, uya = pay - c.y, uza = paz - c.z;
-            const float uxb = pbx - c.x, uyb = pby - c.y, uzb = pbz - c.z;
-            const float uua = __builtin_fmaf(uza, uza, __builtin_fmaf(uya, uya, uxa * uxa));
-            const float uub = __builtin_fmaf(uzb, uzb, __builtin_fmaf(uyb, uyb, uxb * uxb));
-            const float cfa = __builtin_fmaf(uua, kKappa, -c.w), cfb = __builtin_fmaf(uub, kKappa, -c.w);
+            const float pca = __builtin_fmaf(fa.z, c.z, __builtin_fmaf(fa.y, c.y, fa.x * c.x));
+            const float pcb = __builtin_fmaf(fb.z, c.z, __builtin_fmaf(fb.y, c.y, fb.x * c.x));
+            const float ea = __builtin_fmaf(pca, kTwoKappa, -c.w), eb = __builtin_fmaf(pcb, kTwoKappa, -c.w);
             uint32_t mask_a = 0, mask_b = 0;
 #pragma unroll
             for (int v = 0; v < KV; ++v) {
@@ -303,41 +338,41 @@ __global__ void __launch_bounds__(kBlock, 6) shadow_uniform_kernel(DevScene S, D
               for (int e = 0; e < 4; ++e) {
                 const int k = v * 4 + e;
                 const float kv = (&row.x)[e];
-                const float ha = Pa[k] - kv, hb = Pb[k] - kv;
-                if (__builtin_fmaf(ha, ha, -cfa) >= thr) mask_a |= 1u << k;
-                if (__builtin_fmaf(hb, hb, -cfb) >= thr) mask_b |= 1u << k;
+                const float ha = fa.P[k] - kv, hb = fb.P[k] - kv;
+                if (__builtin_fmaf(ha, ha, ea) >= fa.thrp) mask_a |= 1u << k;
+                if (__builtin_fmaf(hb, hb, eb) >= fb.thrp) mask_b |= 1u << k;
               }
             }
-            if (!live_a) mask_a = 0;
-            if (!live_b) mask_b = 0;
             mask_a &= ~occl_a;
             mask_b &= ~occl_b;
             if (wave_any((mask_a | mask_b) != 0)) {
               const DevObject& ob = S.objects[S.sph_object[base + j + g]];
-              for (uint32_t r = 0; r < nb; ++r) {
-                if ((mask_a >> r) & 1u) {
-                  ++n_exact;
-                  if (shadow_ray_blocked(ob, S.lights[kb + r], p_a)) occl_a |= 1u << r;
-                }
-                if ((mask_b >> r) & 1u) {
-                  ++n_exact;
-                  if (shadow_ray_blocked(ob, S.lights[kb + r], p_b)) occl_b |= 1u << r;
-                }
+              if (mask_a) {
+                const V3 p = load_p(pa);
+                for (uint32_t r = 0; r < nb; ++r)
+                  if ((mask_a >> r) & 1u) {
+                    ++n_exact;
+                    if (shadow_ray_blocked(ob, S.lights[kb + r], p)) occl_a |= 1u << r;
+                  }
+              }
+              if (mask_b) {
+                const V3 p = load_p(pb);
+                for (uint32_t r = 0; r < nb; ++r)
+                  if ((mask_b >> r) & 1u) {
+                    ++n_exact;
+                    if (shadow_ray_blocked(ob, S.lights[kb + r], p)) occl_b |= 1u << r;
+                  }
               }
             }
           }
           // a pixel whose first light is blocked needs nothing more: park it
           if (live_a && (occl_a & 1u)) {
             live_a = false;
-            pax = pay = paz = 1.0e15f;
-#pragma unroll
-            for (int k = 0; k < KW; ++k) Pa[k] = 0.0f;
+            park(fa);
           }
           if (live_b && (occl_b & 1u)) {
             live_b = false;
-            pbx = pby = pbz = 1.0e15f;
-#pragma unroll
-            for (int k = 0; k < KW; ++k) Pb[k] = 0.0f;
+            park(fb);
           }
           wave_live = wave_any(live_a || live_b);
           if (!wave_live) break;
@@ -371,7 +406,6 @@ __global__ void __launch_bounds__(kBlock, 6) shadow_uniform_kernel(DevScene S, D
   n_exact = wave_sum(n_exact);
   if ((threadIdx.x & 63u) == 0) atomicAdd(&counters->exact_tests, (unsigned long long)n_exact);
 }
-
 
 // Kernel 2b: shadow rays for arbitrary lights (some w != 0): one pixel per lane, per-lane
 // line directions, LB lights fused.

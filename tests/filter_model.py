@@ -2,7 +2,8 @@
 
 Mirrors, operation for operation, the record construction in csrc/rtk_api.hip
 (rtk_scene_upload), `prep_primary_kernel`, `make_filter_ray`, `filter_threshold`,
-`sweep_primary` and `sweep_filter` in csrc/rtk_kernels.hip.  A fused multiply-add is
+`sweep_primary` and `sweep_filter` in csrc/rtk_sweeps.h, and the tabulated shadow filter
+(`PixelFilter`/`arm` and the hot loop of `shadow_uniform_kernel`) in csrc/rtk_opaque.hip.  A fused multiply-add is
 modelled as an f64 multiply-add rounded once to f32 (the f64 product of two f32 values is
 exact, so this differs from a true fma only in rare double-rounding cases).
 """
@@ -100,3 +101,45 @@ class FilterScene:
         cf = fma(uu, KAPPA, -r2)
         h = fma(uz, ex(g[:, 2]), fma(uy, ex(g[:, 1]), fma(ux, ex(g[:, 0]), (r2 * ex(rho)).astype(F))))
         return fma(h, h, -cf) >= ex(thr)
+
+    # ---- tabulated shadow filter (lights with w = 0) ---------------------------------
+    def tabulated_pass(self, p, light_xyz, pairwise=True):
+        """Shadow ray from p [rays,3] towards ONE w = 0 light at light_xyz; ray i vs sphere i."""
+        p = np.asarray(p, np.float64)
+        Lv = np.asarray(light_xyz, np.float64)
+        inv = 1.0 / np.sqrt((Lv * Lv).sum())
+        gd = Lv * inv
+        rho_d = -inv
+        lf = np.array([gd[0], gd[1], gd[2], rho_d]).astype(F)
+        # records built at scene upload
+        cfd = self.cf.astype(np.float64)
+        cc = float(KAPPA) * (cfd * cfd).sum(axis=1) - self.r2.astype(np.float64)
+        ccf = cc.astype(F)
+        ccf = np.where(ccf.astype(np.float64) > cc, np.nextafter(ccf, F(-np.inf)), ccf)
+        ccf = np.nextafter(ccf, F(-np.inf)).astype(F)
+        K = (cfd @ gd - self.r2.astype(np.float64) * rho_d).astype(F)
+        # per-pixel set-up (arm)
+        pc = p - self.center
+        x, y, z = pc[:, 0].astype(F), pc[:, 1].astype(F), pc[:, 2].astype(F)
+        P = fma(z, lf[2], fma(y, lf[1], (x * lf[0]).astype(F)))
+        rho_max = float(np.abs(lf[3]) * F(1.0001))
+        pn2 = (pc * pc).sum(axis=1)
+        pn = np.sqrt(pn2)
+        B = float(self.r2_max) * rho_max
+        dh = float(EPS32) * (6.0 * pn + 2.0 * float(self.c_max) + 2.0 * B) * 1.01
+        hmax = pn + float(self.c_max) + B
+        cm2 = float(self.c_max) ** 2
+        extra = 2.0 * hmax * dh + dh * dh + 6.0 * float(EPS32) * (pn2 + cm2 + float(self.r2_max)) * 1.01
+        thr = self.threshold(p, np.full(len(p), rho_max)).astype(np.float64) - extra * 1.001
+        pp = x.astype(np.float64) ** 2 + y.astype(np.float64) ** 2 + z.astype(np.float64) ** 2
+        t = float(KAPPA) * pp + thr
+        tf = t.astype(F)
+        tf = np.where(tf.astype(np.float64) > t, np.nextafter(tf, F(-np.inf)), tf)
+        thrp = np.nextafter(tf, F(-np.inf)).astype(F)
+        # hot loop
+        two_kappa = F(2.0) * KAPPA
+        assert pairwise
+        pcd = fma(z, self.cf[:, 2], fma(y, self.cf[:, 1], (x * self.cf[:, 0]).astype(F)))
+        e = fma(pcd, two_kappa, -ccf)
+        h = (P - K).astype(F)
+        return fma(h, h, e) >= thrp

@@ -92,6 +92,26 @@ def test_shadow_filter_keeps_every_grazing_hit(scale, light_w):
         assert delta < 1e-6 or hit.mean() > 0.9  # below that the f64 discriminant itself is rounding noise
 
 
+@pytest.mark.parametrize("scale", [2.0, 50.0, 400.0, 3000.0])
+def test_tabulated_shadow_filter_keeps_every_grazing_hit(scale):
+    """Lights with w = 0: the filter of the three-kernel path (tabulated K, expanded |u|^2)."""
+    rng = np.random.default_rng(int(scale) + 5)
+    n = 20000
+    p = rng.normal(size=(n, 3)) * scale * 0.4
+    L = np.array([0.3, 1.0, -0.2]) * scale + rng.normal(size=3)
+    s = rng.uniform(-0.5, 1.5, size=(n, 1))
+    c = p + (L - p) * s + rng.normal(size=(n, 3)) * rng.uniform(0.01, 3.0, size=(n, 1))
+    lv = L - p
+    m = np.sqrt((lv * lv).sum(axis=1) + 1.0)
+    d, dw = lv / m[:, None], -1.0 / m
+    Rstar = grazing_radius(p, d, dw, c)
+    for delta in DELTAS:
+        R = Rstar * (1.0 + delta)
+        hit = exact_disc(p, d, dw, c, R) >= 0
+        keep = FilterScene(c, R).tabulated_pass(p, L)
+        assert not (hit & ~keep).any(), f"dropped {int((hit & ~keep).sum())} at delta={delta}"
+
+
 def test_secondary_ray_filter_with_unnormalised_directions():
     rng = np.random.default_rng(7)
     n = 20000
@@ -149,3 +169,12 @@ def test_filter_stays_selective_on_a_c4_like_scene(rtk):
                                np.full(len(c), -1.0 / m[i]), c, R) >= 0 for i in range(256)])
     assert not (hit & ~keep).any()
     assert keep.sum() <= 2.0 * hit.sum() + 64, (int(keep.sum()), int(hit.sum()))
+    # the tabulated form trades some selectivity for speed; it must stay within a small factor
+    keep_t = np.stack([fs_rows(fs, p[i], L, len(c)) for i in range(64)])
+    assert not (hit[:64] & ~keep_t).any()
+    assert keep_t.sum() <= 3.0 * hit[:64].sum() + 64, (int(keep_t.sum()), int(hit[:64].sum()))
+
+
+def fs_rows(fs, point, light, n):
+    """Tabulated filter of one shading point against all n spheres."""
+    return fs.tabulated_pass(np.broadcast_to(point, (n, 3)), light)

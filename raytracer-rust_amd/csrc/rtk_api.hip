@@ -249,8 +249,8 @@ int rtk_create(int device_id, rtk_context** out) {
   ctx->device = device_id;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&ctx->ev_start)) != hipSuccess || (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
-      (e = hipMalloc((void**)&ctx->d_counters, sizeof(rtk::DevCounters))) != hipSuccess ||
-      (e = hipMemset(ctx->d_counters, 0, sizeof(rtk::DevCounters))) != hipSuccess) {
+      (e = hipMalloc((void**)&ctx->d_counters, sizeof(rtk::DevCounters) * rtk::kCounterShards)) != hipSuccess ||
+      (e = hipMemset(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards)) != hipSuccess) {
     rtk_destroy(ctx);
     return fail_hip(e, "rtk_create");
   }
@@ -518,7 +518,7 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
 
   RTK_HIP(hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-  RTK_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters), st));
+  RTK_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, st));
   RTK_HIP(rtk::launch_prep_primary(st, scene->dev, cam, scene->d_prim));
   const bool opaque = !scene->dev.any_secondary;
   if (opaque) {
@@ -557,13 +557,15 @@ int rtk_get_stats(rtk_context* ctx, rtk_stats* stats) {
   RTK_HIP(hipEventSynchronize(ctx->ev_stop));
   float ms = 0.f;
   RTK_HIP(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
-  rtk::DevCounters c;
-  RTK_HIP(hipMemcpyAsync(&c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost, ctx->last_stream));
+  rtk::DevCounters shards[rtk::kCounterShards];
+  RTK_HIP(hipMemcpyAsync(shards, ctx->d_counters, sizeof shards, hipMemcpyDeviceToHost, ctx->last_stream));
   RTK_HIP(hipStreamSynchronize(ctx->last_stream));
-  stats->rays_primary = c.rays_primary;
-  stats->rays_shadow = c.rays_shadow;
-  stats->rays_secondary = c.rays_secondary;
-  stats->exact_tests = c.exact_tests;
+  for (const rtk::DevCounters& c : shards) {
+    stats->rays_primary += c.rays_primary;
+    stats->rays_shadow += c.rays_shadow;
+    stats->rays_secondary += c.rays_secondary;
+    stats->exact_tests += c.exact_tests;
+  }
   stats->kernel_ms = ms;
   return RTK_OK;
 }
@@ -619,7 +621,7 @@ int rtk_trace_rays(rtk_context* ctx, rtk_scene_handle* scene, const double* orig
   hipStream_t st = ctx->stream;
   if (e == hipSuccess) e = hipMemcpyAsync(d_o, origins, n * 4 * sizeof(double), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_d, directions, n * 4 * sizeof(double), hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters), st);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, st);
   if (e == hipSuccess) e = hipEventRecord(ctx->ev_start, st);
   if (e == hipSuccess) e = rtk::launch_trace_rays(st, scene->dev, d_o, d_d, n, d_c, ctx->d_counters);
   if (e == hipSuccess) e = hipEventRecord(ctx->ev_stop, st);

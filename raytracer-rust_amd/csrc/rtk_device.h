@@ -75,9 +75,15 @@ struct DevCamera {
   double origin[3];   // inverse * point(0,0,0)
 };
 
+// Ray counters.  Every wavefront adds its counts with atomics; one address takes about one
+// atomic per 12 ns, so the counters are sharded (workgroup b adds to shard b % kCounterShards,
+// the host sums the shards) -- a short kernel of 10^5 wavefronts would otherwise spend its
+// whole run time queueing on one word.
+constexpr int kCounterShards = 256;
 struct DevCounters {
   unsigned long long rays_primary, rays_shadow, rays_secondary, exact_tests;
 };
+__device__ __forceinline__ DevCounters* counter_shard(DevCounters* base) { return base + (blockIdx.x % kCounterShards); }
 
 // Intermediate records of the three-kernel path, one entry per pixel of the launch
 // (local tile k, slot s -> index k*256 + s).

@@ -229,10 +229,10 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera
   c_secondary = wave_sum(c_secondary);
   c_exact = wave_sum(c_exact);
   if (lane == 0) {
-    atomicAdd(&counters->rays_primary, (unsigned long long)c_primary);
-    atomicAdd(&counters->rays_shadow, (unsigned long long)c_shadow);
-    atomicAdd(&counters->rays_secondary, (unsigned long long)c_secondary);
-    atomicAdd(&counters->exact_tests, (unsigned long long)c_exact);
+    atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)c_primary);
+    atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)c_shadow);
+    atomicAdd(&counter_shard(counters)->rays_secondary, (unsigned long long)c_secondary);
+    atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)c_exact);
   }
 }
 
@@ -261,10 +261,10 @@ __global__ void __launch_bounds__(kBlock) trace_rays_kernel(DevScene S, const do
   c_secondary = wave_sum(c_secondary);
   c_exact = wave_sum(c_exact);
   if ((threadIdx.x & 63u) == 0) {
-    atomicAdd(&counters->rays_primary, (unsigned long long)c_primary);
-    atomicAdd(&counters->rays_shadow, (unsigned long long)c_shadow);
-    atomicAdd(&counters->rays_secondary, (unsigned long long)c_secondary);
-    atomicAdd(&counters->exact_tests, (unsigned long long)c_exact);
+    atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)c_primary);
+    atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)c_shadow);
+    atomicAdd(&counter_shard(counters)->rays_secondary, (unsigned long long)c_secondary);
+    atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)c_exact);
   }
 }
 

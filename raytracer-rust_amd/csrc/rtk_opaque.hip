@@ -156,8 +156,8 @@ __global__ void __launch_bounds__(kBlock, 8) primary_kernel(DevScene S, DevCamer
   unsigned n_primary = wave_sum((pa.valid ? 1u : 0u) + (pb.valid ? 1u : 0u));
   n_exact = wave_sum(n_exact);
   if ((threadIdx.x & 63u) == 0) {
-    atomicAdd(&counters->rays_primary, (unsigned long long)n_primary);
-    atomicAdd(&counters->exact_tests, (unsigned long long)n_exact);
+    atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)n_primary);
+    atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
   }
 }
 
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel
   if (pa.in_range) B.shadow[pa.local] = (uint8_t)((shadow_a ? 0x80u : 0u) | rays_a);
   if (pb.in_range) B.shadow[pb.local] = (uint8_t)((shadow_b ? 0x80u : 0u) | rays_b);
   n_exact = wave_sum(n_exact);
-  if ((threadIdx.x & 63u) == 0) atomicAdd(&counters->exact_tests, (unsigned long long)n_exact);
+  if ((threadIdx.x & 63u) == 0) atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
 }
 
 // Kernel 2b: shadow rays for arbitrary lights (some w != 0): one pixel per lane, per-lane
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(kBlock, 4) shadow_general_kernel(DevScene S, D
   const bool in_shadow = shadow_sweeps<LB>(S, s_buf, hit, p, rays, n_exact);
   B.shadow[px.local] = (uint8_t)((in_shadow ? 0x80u : 0u) | rays);
   n_exact = wave_sum(n_exact);
-  if ((threadIdx.x & 63u) == 0) atomicAdd(&counters->exact_tests, (unsigned long long)n_exact);
+  if ((threadIdx.x & 63u) == 0) atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
 }
 
 // ------------------------------------------------------------------------------------
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, 
     }
   }
   n_shadow = wave_sum(n_shadow);
-  if (lane == 0) atomicAdd(&counters->rays_shadow, (unsigned long long)n_shadow);
+  if (lane == 0) atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)n_shadow);
 }
 
 // ------------------------------------------------------------------------------------

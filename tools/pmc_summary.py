@@ -1,0 +1,46 @@
+"""Per-kernel means of the rocprofv3 PMC passes written by tools/profile.sh, with derived figures.
+usage: python tools/pmc_summary.py gpurun_out/prof_<tag> [--json out.json]"""
+import collections, csv, glob, json, sys
+
+src = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+meta = {}
+for f in glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "rtk::" not in name:
+            continue
+        agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        meta[name] = {"VGPR": r["VGPR_Count"], "LDS": r["LDS_Block_Size"], "scratch": r["Scratch_Size"], "grid": r["Grid_Size"]}
+times = {}
+for f in glob.glob(f"{src}/trace/*/*_kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        name = r["Name"].split("(")[0].replace("void ", "")
+        if "rtk::" in name:
+            times[name] = float(r["AverageNs"]) / 1e6
+out = {}
+for name, counters in sorted(agg.items()):
+    m = {k: sum(v) / len(v) for k, v in counters.items()}
+    d = dict(meta[name])
+    d["avg_ms"] = times.get(name)
+    d.update(m)
+    if "GRBM_GUI_ACTIVE" in m and m["GRBM_GUI_ACTIVE"] > 0:
+        cyc = m["GRBM_GUI_ACTIVE"] / 8.0          # summed over the 8 XCDs
+        d["cycles"] = cyc
+        if d["avg_ms"]:
+            d["clock_GHz"] = cyc / (d["avg_ms"] * 1e6)
+        simd_cycles = 1024.0 * cyc
+        if "SQ_INSTS_VALU" in m:
+            d["valu_issue_util"] = m["SQ_INSTS_VALU"] * 2.0 / simd_cycles   # one wave64 VALU instruction = 2 cycles of a SIMD
+        if "SQ_WAVE_CYCLES" in m:
+            d["avg_waves_per_simd"] = m["SQ_WAVE_CYCLES"] * 4.0 / simd_cycles
+        if "SQ_LDS_IDX_ACTIVE" in m:
+            d["lds_busy"] = m["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc)
+    if "SQ_WAVES" in m and "SQ_INSTS_VALU" in m:
+        d["valu_per_wave"] = m["SQ_INSTS_VALU"] / m["SQ_WAVES"]
+    out[name] = d
+    print(name)
+    for k, v in d.items():
+        print(f"   {k:24s} {v:.6g}" if isinstance(v, float) else f"   {k:24s} {v}")
+if "--json" in sys.argv:
+    json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)

@@ -146,6 +146,8 @@ struct rtk_scene_handle {
   void* d_sph_object = nullptr;
   void* d_plane_object = nullptr;
   float4* d_prim = nullptr;  // primary-ray filter records (rebuilt per camera)
+  float4* d_prim_ball = nullptr;  // camera-ray records of the wavefront-level cone test (rebuilt per camera)
+  void* d_sph_ball = nullptr;
   void* d_light_filter = nullptr;
   void* d_k_table = nullptr;
   void* d_sph_tab = nullptr;
@@ -279,7 +281,7 @@ void rtk_scene_release(rtk_context* ctx, rtk_scene_handle* h) {
   if (!h) return;
   if (ctx) (void)hipSetDevice(ctx->device);
   void* ptrs[] = {h->d_objects, h->d_lights, h->d_filter, h->d_exact, h->d_sph_object, h->d_plane_object, h->d_prim,
-                  h->d_light_filter, h->d_k_table, h->d_sph_tab};
+                  h->d_light_filter, h->d_k_table, h->d_sph_tab, h->d_prim_ball, h->d_sph_ball};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -346,7 +348,7 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
 
   // FP32 filter records, recentred on the middle of the sphere centres' bounding box
   const uint32_t n_sph = (uint32_t)sph_exact.size();
-  const uint32_t n_pad = round_up_to(n_sph, kGroup);
+  const uint32_t n_pad = round_up_to(n_sph, kBundle);
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   for (uint32_t i = 0; i < n_sph; ++i) {
     const double c[3] = {sph_exact[i].x, sph_exact[i].y, sph_exact[i].z};
@@ -376,6 +378,17 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
     r2_max = std::fmax(r2_max, r2);
     r_max = std::fmax(r_max, round_up(R));
     c_max = std::fmax(c_max, round_up(std::sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]) * 1.0001));
+  }
+
+  // records of the wavefront-level test: centre and (not squared) inflated radius
+  std::vector<float4> sph_ball(n_pad);
+  for (uint32_t j = 0; j < n_pad; ++j) {
+    if (j >= n_sph) {
+      sph_ball[j] = make_float4(0.f, 0.f, 0.f, -1.0e30f);
+      continue;
+    }
+    const float4 f = filter[j];
+    sph_ball[j] = make_float4(f.x, f.y, f.z, round_up(std::sqrt((double)f.w) * (1.0 + 1e-7)));
   }
 
   // Lights with w == 0 (what scene files produce, src/loader.rs:35-40): the shadow-ray line
@@ -442,7 +455,9 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   upload(&h->d_light_filter, light_filter.data(), light_filter.size() * sizeof(float4));
   upload(&h->d_k_table, k_table.data(), k_table.size() * sizeof(float));
   upload(&h->d_sph_tab, sph_tab.data(), sph_tab.size() * sizeof(float4));
+  upload(&h->d_sph_ball, sph_ball.data(), sph_ball.size() * sizeof(float4));
   if (e == hipSuccess && n_pad) e = hipMalloc((void**)&h->d_prim, n_pad * sizeof(float4));
+  if (e == hipSuccess && n_pad) e = hipMalloc((void**)&h->d_prim_ball, n_pad * sizeof(float4));
   if (e != hipSuccess) {
     rtk_scene_release(ctx, h);
     return fail_hip(e, "rtk_scene_upload");
@@ -457,6 +472,7 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   d.light_filter = (const float4*)h->d_light_filter;
   d.k_table = (const float4*)h->d_k_table;
   d.sph_tab = (const float4*)h->d_sph_tab;
+  d.sph_ball = (const float4*)h->d_sph_ball;
   d.lights_uniform = lights_uniform ? 1u : 0u;
   d.k_width = k_width;
   d.n_objects = scene->n_objects;
@@ -519,7 +535,7 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
   RTK_HIP(hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   RTK_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, st));
-  RTK_HIP(rtk::launch_prep_primary(st, scene->dev, cam, scene->d_prim));
+  RTK_HIP(rtk::launch_prep_primary(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball));
   const bool opaque = !scene->dev.any_secondary;
   if (opaque) {
     // intermediate hit / shadow records: one entry per pixel of this launch
@@ -540,7 +556,7 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
   }
   RTK_HIP(hipEventRecord(ctx->ev_start, st));
   if (opaque)
-    RTK_HIP(rtk::launch_render_opaque(st, scene->dev, cam, scene->d_prim, t, ctx->opaque, ctx->d_counters));
+    RTK_HIP(rtk::launch_render_opaque(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball, t, ctx->opaque, ctx->d_counters));
   else
     RTK_HIP(rtk::launch_render(st, scene->dev, cam, scene->d_prim, t, ctx->d_counters));
   RTK_HIP(hipEventRecord(ctx->ev_stop, st));

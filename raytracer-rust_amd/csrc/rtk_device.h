@@ -10,7 +10,8 @@ namespace rtk {
 
 constexpr int kBlock = 256;      // threads per workgroup = one 32x8 pixel tile (4 waves of 8x8)
 constexpr int kChunk = 1024;     // sphere filter records staged in LDS per pass (16 KiB)
-constexpr int kGroup = 8;        // records per wavefront early-out branch
+constexpr int kGroup = 8;        // records per wavefront early-out branch (one ray per lane)
+constexpr int kBundle = 64;      // records per wavefront-level test (one sphere per lane); arrays are padded to this
 constexpr int kMaxDepth = 8;     // == RTK_MAX_DEPTH_LIMIT
 constexpr int kMaxLightBatch = 8;
 
@@ -54,6 +55,7 @@ struct DevScene {
   const float4* light_filter;   // per light: unit line direction g = G/|G| and rho = (w-1)/|G| for G = L.xyz (w = 0 lights)
   const float4* k_table;        // [batch][sphere][k_width]: c_j.g_k - R_j'^2 rho_k, only when lights_uniform
   const float4* sph_tab;        // {cx, cy, cz, kappa |c|^2 - R'^2}: sphere record of the tabulated shadow filter
+  const float4* sph_ball;       // {cx, cy, cz, R'}: record of the wavefront-level test; padding has R' = -1e30
   uint32_t n_objects, n_lights, n_spheres, n_spheres_padded, n_planes;
   uint32_t max_depth;
   uint32_t track_n1;     // some transparent object has refractivity != the others: keep n1

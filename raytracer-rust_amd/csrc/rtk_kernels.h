@@ -9,8 +9,9 @@ namespace rtk {
 // Lights fused per shadow sweep for a scene with n_lights lights (1, 2, 4 or 8).
 int light_batch_for(uint32_t n_lights);
 
-// Rebuilds the primary-ray filter records for camera C into prim[n_spheres_padded].
-hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamera& C, float4* prim);
+// Rebuilds the camera-ray records for camera C: prim[n_spheres_padded] (per-ray filter) and
+// prim_ball[n_spheres_padded] (wavefront-level cone test).
+hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamera& C, float4* prim, float4* prim_ball);
 
 // Renders the tiles selected by T.
 hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim, const RenderTarget& T,
@@ -19,7 +20,8 @@ hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, 
 // Same for scenes without reflective or transparent materials: three lean kernels
 // (camera rays, shadow rays, shading) with intermediate records in B.
 hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
-                                const RenderTarget& T, const OpaqueBuffers& B, DevCounters* counters);
+                                const float4* prim_ball, const RenderTarget& T, const OpaqueBuffers& B,
+                                DevCounters* counters);
 
 // Traces n caller-supplied rays (device pointers, n x 4 doubles in, n x 3 doubles out).
 hipError_t launch_trace_rays(hipStream_t st, const DevScene& S, const double* origins, const double* directions, uint64_t n,

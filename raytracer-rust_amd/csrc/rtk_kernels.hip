@@ -268,11 +268,13 @@ __global__ void __launch_bounds__(kBlock) trace_rays_kernel(DevScene S, const do
   }
 }
 
-// Per-camera record of the primary filter: one thread per (padded) sphere.
-__global__ void __launch_bounds__(kBlock) prep_primary_kernel(DevScene S, DevCamera C, float4* __restrict__ prim) {
+// Per-camera records of the camera-ray tests: one thread per (padded) sphere.
+__global__ void __launch_bounds__(kBlock) prep_primary_kernel(DevScene S, DevCamera C, float4* __restrict__ prim,
+                                                              float4* __restrict__ prim_ball) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= S.n_spheres_padded) return;
-  // padding records repeat the last real sphere (see rtk_scene_upload)
+  // padding of the per-ray records repeats the last real sphere (see rtk_scene_upload);
+  // padding of the wavefront-level records can never pass (negative radius)
   const double4 s = S.sph_exact[min(i, S.n_spheres - 1u)];
   const double Lx = s.x - C.origin[0], Ly = s.y - C.origin[1], Lz = s.z - C.origin[2];
   const double LL = Lx * Lx + Ly * Ly + Lz * Lz;
@@ -285,6 +287,13 @@ __global__ void __launch_bounds__(kBlock) prep_primary_kernel(DevScene S, DevCam
   if ((double)ccf > cc) ccf = nextafterf(ccf, -INFINITY);
   ccf = nextafterf(ccf, -INFINITY);
   prim[i] = make_float4((float)Lx, (float)Ly, (float)Lz, ccf);
+  if (prim_ball) {
+    // cone test: 16 eps |L| covers the rounding of L, of the axis and of the distance arithmetic
+    const double Rs = s.w * (1.0 + 1e-6) + 16.0 * eps * sqrt(LL);
+    float rsf = (float)Rs;
+    if ((double)rsf < Rs) rsf = nextafterf(rsf, INFINITY);
+    prim_ball[i] = i < S.n_spheres ? make_float4((float)Lx, (float)Ly, (float)Lz, rsf) : make_float4(0.f, 0.f, 0.f, -1.0f);
+  }
 }
 
 // Rebuilds row-major frames from `world` compact tile buffers laid end to end.
@@ -333,10 +342,10 @@ int light_batch_for(uint32_t n_lights) {
   return 8;
 }
 
-hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamera& C, float4* prim) {
+hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamera& C, float4* prim, float4* prim_ball) {
   if (S.n_spheres_padded == 0) return hipSuccess;
   dim3 grid((S.n_spheres_padded + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(prep_primary_kernel, grid, dim3(kBlock), 0, st, S, C, prim);
+  hipLaunchKernelGGL(prep_primary_kernel, grid, dim3(kBlock), 0, st, S, C, prim, prim_ball);
   return hipGetLastError();
 }
 

@@ -15,6 +15,18 @@
 // Arithmetic of the decisions is unchanged from the single-kernel path (rtk_kernels.hip):
 // conservative FP32 filter, then the reference's own f64 formulas with contraction off.
 //
+// Wavefront-level early-out.  The 64 rays of a wavefront patch (8x8 pixels) are coherent:
+// camera rays fill a narrow cone, shadow rays towards a w = 0 light are parallel lines
+// through a small ball of shading points.  Each sweep over the object list therefore runs
+// in two levels:
+//   level 1  the lanes take 64 DIFFERENT spheres each and test them against the patch's
+//            bundle (cone / fattened line), about 14 VALU instructions per 64 spheres per
+//            bundle; a ballot gives the spheres some ray of the patch might touch;
+//   level 2  only for those, the per-ray FP32 filter (one ray per lane, the sphere
+//            broadcast), then f64 on the candidates it keeps.
+// Both levels are conservative, every (ray, sphere) pair of the object list is covered by
+// one of the tests, and the f64 decisions are the same as before.
+//
 // When every light of the scene has w = 0 (lights loaded from scene files,
 // src/loader.rs:35-40) the shadow ray's line direction g_k = L_k/|L_k| is the same for
 // every shading point, so the per-(sphere, light) part of the filter is tabulated at scene
@@ -31,7 +43,6 @@
 
 namespace rtk {
 
-constexpr int kShadowChunk = 512;  // records per LDS pass of the shadow kernels
 
 // Hides a value from the optimiser so that what is computed from it is recomputed where
 // it is used instead of being kept live across a sweep.
@@ -63,15 +74,48 @@ __device__ __forceinline__ PixelRef pixel_ref(const RenderTarget& T, const DevCa
 }
 
 // ------------------------------------------------------------------------------------
+// Bundles.  All fields are wavefront-uniform (they live in SGPRs).
+
+// Cone around the unit camera rays of one patch: axis a, tan and sec of the half-angle.
+struct Cone {
+  float ax, ay, az, tan_t, sec_t;
+};
+__device__ __forceinline__ Cone make_cone(float dx, float dy, float dz) {
+  Cone c;
+  float sx = wave_sum_f(dx), sy = wave_sum_f(dy), sz = wave_sum_f(dz);
+  const float inv = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz);
+  c.ax = wave_uniform(sx * inv), c.ay = wave_uniform(sy * inv), c.az = wave_uniform(sz * inv);
+  const float along = dx * c.ax + dy * c.ay + dz * c.az;
+  const float qx = dx - along * c.ax, qy = dy - along * c.ay, qz = dz - along * c.az;
+  const float across = sqrtf(qx * qx + qy * qy + qz * qz);
+  // the slack covers the FP32 rounding of the directions and of this computation
+  const float t = along > 0.0f ? across / along : 3.0e38f;
+  c.tan_t = wave_uniform(wave_max_f(t) * (1.0f + 1.0e-5f) + 2.0e-6f);
+  c.sec_t = wave_uniform(sqrtf(1.0f + c.tan_t * c.tan_t) * (1.0f + 1.0e-6f));
+  return c;
+}
+// Can some ray of the cone (apex at the camera) reach the ball {L, Rs}?  With s = L.a and
+// d the distance of L from the axis: d cos(t) - s sin(t) <= Rs.  One sphere per lane.
+__device__ __forceinline__ bool cone_reaches(const Cone& c, float4 ball) {
+  const float s = __builtin_fmaf(ball.z, c.az, __builtin_fmaf(ball.y, c.ay, ball.x * c.ax));
+  const float qx = __builtin_fmaf(-s, c.ax, ball.x), qy = __builtin_fmaf(-s, c.ay, ball.y), qz = __builtin_fmaf(-s, c.az, ball.z);
+  const float d2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+  const float rr = __builtin_fmaf(s, c.tan_t, ball.w * c.sec_t);
+  return rr >= 0.0f && __builtin_fmaf(rr, rr, -d2) >= 0.0f;
+}
+
+// ------------------------------------------------------------------------------------
 // Kernel 1: camera rays.  Workgroup b owns local tiles 2b' and 2b'+1 (bottom of the frame
-// first); each lane traces the same slot of both tiles.
+// first); each lane traces the same slot of both tiles, each wavefront two 8x8 patches.
 __global__ void __launch_bounds__(kBlock, 8) primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
-                                                           RenderTarget T, OpaqueBuffers B, DevCounters* counters) {
+                                                           const float4* __restrict__ prim_ball, RenderTarget T,
+                                                           OpaqueBuffers B, DevCounters* counters) {
   __shared__ float4 s_buf[kChunk];
   const uint32_t pairs = (T.n_local_tiles + 1u) / 2u;
   const uint32_t pr = pairs - 1u - blockIdx.x;
   const PixelRef pa = pixel_ref(T, C, 2u * pr), pb = pixel_ref(T, C, 2u * pr + 1u);
   const V3 origin = ld3(C.origin);
+  const uint32_t lane = threadIdx.x & 63u;
 
   Closest best_a, best_b;
   closest_init(best_a);
@@ -89,56 +133,49 @@ __global__ void __launch_bounds__(kBlock, 8) primary_kernel(DevScene S, DevCamer
       if (pb.valid && intersect_object(S.objects[obj], origin, db, 0.0, t0, t1)) closest_consider(best_b, t0, obj, false);
     }
   }
-  const bool any_valid = pa.valid || pb.valid;
+  // pixels outside the frame still have well-defined directions; they only widen the cone a little
+  const Cone cone_a = make_cone(ax, ay, az), cone_b = make_cone(bx, by, bz);
+  const bool live_a = wave_any(pa.valid), live_b = wave_any(pb.valid);
+
   for (uint32_t base = 0; base < S.n_spheres_padded; base += kChunk) {
     const uint32_t count = min((uint32_t)kChunk, S.n_spheres_padded - base);
-    stage_chunk(s_buf, prim, base, count);
-    if (!wave_any(any_valid)) continue;
-    for (uint32_t j = 0; j < count; j += kGroup) {
-      float4 q[kGroup];
-#pragma unroll
-      for (int g = 0; g < kGroup; ++g) q[g] = s_buf[j + g];
-      float m = -1.0f;
-#pragma unroll
-      for (int g = 0; g < kGroup; ++g) {
-        float ta = q[g].x * ax;
-        ta = __builtin_fmaf(q[g].y, ay, ta);
-        ta = __builtin_fmaf(q[g].z, az, ta);
-        float tb = q[g].x * bx;
-        tb = __builtin_fmaf(q[g].y, by, tb);
-        tb = __builtin_fmaf(q[g].z, bz, tb);
-        m = fmaxf(m, fmaxf(__builtin_fmaf(ta, ta, -q[g].w), __builtin_fmaf(tb, tb, -q[g].w)));
-      }
-      if (wave_any(m >= 0.0f)) {
-#pragma unroll 1
-        for (int g = 0; g < kGroup; ++g) {
-          const float4 r = s_buf[j + g];
-          float ta = r.x * ax;
-          ta = __builtin_fmaf(r.y, ay, ta);
-          ta = __builtin_fmaf(r.z, az, ta);
-          float tb = r.x * bx;
-          tb = __builtin_fmaf(r.y, by, tb);
-          tb = __builtin_fmaf(r.z, bz, tb);
-          const bool pass_a = pa.valid && __builtin_fmaf(ta, ta, -r.w) >= 0.0f;
-          const bool pass_b = pb.valid && __builtin_fmaf(tb, tb, -r.w) >= 0.0f;
-          if (wave_any(pass_a || pass_b)) {
-            const uint32_t obj = S.sph_object[base + j + g];
-            double t0, t1;
-            if (pass_a) {
-              ++n_exact;
-              const V3 d = camera_ray_direction(C, launder(pa.x), pa.y);
-              if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
-                closest_consider(best_a, t0, obj, false);
-                closest_consider(best_a, t1, obj, false);
-              }
+    stage_chunk(s_buf, prim_ball, base, count);
+    if (!(live_a || live_b)) continue;
+    for (uint32_t blk = 0; blk < count; blk += 64u) {
+      // level 1: this lane's sphere against both cones
+      const float4 ball = s_buf[blk + lane];
+      const unsigned long long ma = live_a ? __builtin_amdgcn_ballot_w64(cone_reaches(cone_a, ball)) : 0ull;
+      const unsigned long long mb = live_b ? __builtin_amdgcn_ballot_w64(cone_reaches(cone_b, ball)) : 0ull;
+      // level 2: per-ray filter and exact test for the spheres level 1 kept
+      for (unsigned long long m = ma | mb; m != 0ull; m &= m - 1ull) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+        const uint32_t j = base + blk + bit;
+        const float4 r = prim[j];
+        float ta = r.x * ax;
+        ta = __builtin_fmaf(r.y, ay, ta);
+        ta = __builtin_fmaf(r.z, az, ta);
+        float tb = r.x * bx;
+        tb = __builtin_fmaf(r.y, by, tb);
+        tb = __builtin_fmaf(r.z, bz, tb);
+        const bool pass_a = pa.valid && ((ma >> bit) & 1ull) && __builtin_fmaf(ta, ta, -r.w) >= 0.0f;
+        const bool pass_b = pb.valid && ((mb >> bit) & 1ull) && __builtin_fmaf(tb, tb, -r.w) >= 0.0f;
+        if (wave_any(pass_a || pass_b)) {
+          const uint32_t obj = S.sph_object[j];
+          double t0, t1;
+          if (pass_a) {
+            ++n_exact;
+            const V3 d = camera_ray_direction(C, launder(pa.x), pa.y);
+            if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
+              closest_consider(best_a, t0, obj, false);
+              closest_consider(best_a, t1, obj, false);
             }
-            if (pass_b) {
-              ++n_exact;
-              const V3 d = camera_ray_direction(C, launder(pb.x), pb.y);
-              if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
-                closest_consider(best_b, t0, obj, false);
-                closest_consider(best_b, t1, obj, false);
-              }
+          }
+          if (pass_b) {
+            ++n_exact;
+            const V3 d = camera_ray_direction(C, launder(pb.x), pb.y);
+            if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
+              closest_consider(best_b, t0, obj, false);
+              closest_consider(best_b, t1, obj, false);
             }
           }
         }
@@ -155,7 +192,7 @@ __global__ void __launch_bounds__(kBlock, 8) primary_kernel(DevScene S, DevCamer
   }
   unsigned n_primary = wave_sum((pa.valid ? 1u : 0u) + (pb.valid ? 1u : 0u));
   n_exact = wave_sum(n_exact);
-  if ((threadIdx.x & 63u) == 0) {
+  if (lane == 0) {
     atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)n_primary);
     atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
   }
@@ -230,18 +267,42 @@ __device__ __forceinline__ void arm(PixelFilter<KW>& f, const DevScene& S, V3 p,
 }
 constexpr float kTwoKappa = 2.0f * kKappa;
 
+// Ball around the live shading points of one patch (recentred FP32 coordinates).
+struct Ball {
+  float mx, my, mz, radius;
+  bool any;
+};
+__device__ __forceinline__ Ball make_ball(bool live, float x, float y, float z) {
+  Ball b;
+  const float n = wave_sum_f(live ? 1.0f : 0.0f);
+  b.any = n > 0.0f;
+  const float inv = 1.0f / fmaxf(n, 1.0f);
+  b.mx = wave_uniform(wave_sum_f(live ? x : 0.0f) * inv);
+  b.my = wave_uniform(wave_sum_f(live ? y : 0.0f) * inv);
+  b.mz = wave_uniform(wave_sum_f(live ? z : 0.0f) * inv);
+  const float ex = x - b.mx, ey = y - b.my, ez = z - b.mz;
+  const float far = live ? sqrtf(ex * ex + ey * ey + ez * ez) : 0.0f;
+  b.radius = wave_uniform(wave_max_f(far) * (1.0f + 1.0e-5f));
+  return b;
+}
+
 // ------------------------------------------------------------------------------------
 // Kernel 2a: shadow rays when every light has w = 0.  KW = lights per batch (4 or 8).
+//
+// Level 1 for one light: the patch's shadow lines are parallel to g and pass through the
+// ball {m, rho_w}.  A line through p can touch sphere {c, R} only if its distance from c is
+// at most R_e = R sqrt(1 + 2 |rho| (-s) + R^2 rho^2), s = (p - c).g (the reference's growing
+// ball, see PixelFilter).  Over the ball of points: distance(c, line through m) <=
+// rho_w + R + R |rho| max(rho_w - s_m, 0) + R^3 rho^2 / 2.
 template <int KW>
-__global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel(DevScene S, DevCamera C, RenderTarget T, OpaqueBuffers B,
-                                                                  DevCounters* counters) {
-  constexpr int KV = KW / 4;             // float4 per table row
-  constexpr int kShadowGroup = 16 / KW;  // records per wavefront branch (32 ray-tests either way)
-  __shared__ float4 s_f[kShadowChunk];
-  __shared__ float4 s_k[kShadowChunk * KV];
+__global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel(DevScene S, DevCamera C, RenderTarget T,
+                                                                                OpaqueBuffers B, DevCounters* counters) {
+  constexpr int KV = KW / 4;  // float4 per table row
+  __shared__ float4 s_buf[kChunk];
   const uint32_t pairs = (T.n_local_tiles + 1u) / 2u;
   const uint32_t pr = pairs - 1u - blockIdx.x;
   const PixelRef pa = pixel_ref(T, C, 2u * pr), pb = pixel_ref(T, C, 2u * pr + 1u);
+  const uint32_t lane = threadIdx.x & 63u;
 
   uint32_t obj_a = 0xffffffffu, obj_b = 0xffffffffu;
   if (pa.valid) obj_a = B.hit_obj[pa.local];
@@ -270,7 +331,6 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel
     if (!__syncthreads_or(need_a || need_b)) break;
     const uint32_t nb = min((uint32_t)KW, S.n_lights - kb);
     uint32_t occl_a = 0, occl_b = 0;
-    // planes: exact
     PixelFilter<KW> fa, fb;
     park(fa);
     park(fb);
@@ -293,81 +353,95 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel
     }
     const float4* __restrict__ ktab = S.k_table + (size_t)batch * S.n_spheres_padded * KV;
 
+    // bundles of the two patches; the slack covers the FP32 rounding of points and centres
+    const Ball ball_a = make_ball(live_a, fa.x, fa.y, fa.z), ball_b = make_ball(live_b, fb.x, fb.y, fb.z);
+    float lgx[KW], lgy[KW], lgz[KW], lrho[KW];
+    float grow = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      const float4 lf = S.light_filter[kb + min((uint32_t)k, nb - 1u)];
+      lgx[k] = lf.x, lgy[k] = lf.y, lgz[k] = lf.z, lrho[k] = fabsf(lf.w) * 1.0001f;
+      grow = fmaxf(grow, 0.5f * S.r_max * S.r2_max * lf.w * lf.w);
+    }
+    const float pad_a = ball_a.radius + grow * 1.01f +
+                        16.0f * kEps32 * (fabsf(ball_a.mx) + fabsf(ball_a.my) + fabsf(ball_a.mz) + ball_a.radius + S.c_max);
+    const float pad_b = ball_b.radius + grow * 1.01f +
+                        16.0f * kEps32 * (fabsf(ball_b.mx) + fabsf(ball_b.my) + fabsf(ball_b.mz) + ball_b.radius + S.c_max);
+
+    auto lines_reach = [&](const Ball& bl, float pad, float4 rec) {
+      const float ux = bl.mx - rec.x, uy = bl.my - rec.y, uz = bl.mz - rec.z;
+      const float reach = rec.w + pad;  // R' + rho_w + slack
+      bool pass = false;
+#pragma unroll
+      for (int k = 0; k < KW; ++k) {
+        const float s = __builtin_fmaf(uz, lgz[k], __builtin_fmaf(uy, lgy[k], ux * lgx[k]));
+        const float qx = __builtin_fmaf(-s, lgx[k], ux), qy = __builtin_fmaf(-s, lgy[k], uy), qz = __builtin_fmaf(-s, lgz[k], uz);
+        const float d2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+        const float t = fmaxf(bl.radius - s, 0.0f);
+        const float rr = __builtin_fmaf(t, rec.w * lrho[k], reach) * (1.0f + 4.0f * kEps32);
+        pass |= rr >= 0.0f && __builtin_fmaf(rr, rr, -d2) >= 0.0f;
+      }
+      return pass;
+    };
+
     bool wave_live = wave_any(live_a || live_b);
-    for (uint32_t base = 0; base < S.n_spheres_padded; base += kShadowChunk) {
-      const uint32_t count = min((uint32_t)kShadowChunk, S.n_spheres_padded - base);
-      __syncthreads();
-      for (uint32_t i = threadIdx.x; i < count; i += kBlock) s_f[i] = S.sph_tab[base + i];
-      for (uint32_t i = threadIdx.x; i < count * KV; i += kBlock) s_k[i] = ktab[(size_t)base * KV + i];
-      __syncthreads();
+    for (uint32_t base = 0; base < S.n_spheres_padded; base += kChunk) {
+      const uint32_t count = min((uint32_t)kChunk, S.n_spheres_padded - base);
+      stage_chunk(s_buf, S.sph_ball, base, count);
       if (!wave_live) continue;
-      for (uint32_t j = 0; j < count; j += kShadowGroup) {
-        float4 q[kShadowGroup], kk[kShadowGroup][KV];
+      for (uint32_t blk = 0; blk < count; blk += 64u) {
+        // level 1: this lane's sphere against the line bundles of both patches
+        const float4 rec = s_buf[blk + lane];
+        const unsigned long long ma = wave_any(live_a) ? __builtin_amdgcn_ballot_w64(lines_reach(ball_a, pad_a, rec)) : 0ull;
+        const unsigned long long mb = wave_any(live_b) ? __builtin_amdgcn_ballot_w64(lines_reach(ball_b, pad_b, rec)) : 0ull;
+        bool changed = false;
+        // level 2: per-ray tabulated filter, then the exact test
+        for (unsigned long long m = ma | mb; m != 0ull; m &= m - 1ull) {
+          const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+          const uint32_t j = base + blk + bit;
+          const float4 c = S.sph_tab[j];
+          const float pca = __builtin_fmaf(fa.z, c.z, __builtin_fmaf(fa.y, c.y, fa.x * c.x));
+          const float pcb = __builtin_fmaf(fb.z, c.z, __builtin_fmaf(fb.y, c.y, fb.x * c.x));
+          const float ea = __builtin_fmaf(pca, kTwoKappa, -c.w), eb = __builtin_fmaf(pcb, kTwoKappa, -c.w);
+          uint32_t mask_a = 0, mask_b = 0;
 #pragma unroll
-        for (int g = 0; g < kShadowGroup; ++g) {
-          q[g] = s_f[j + g];
+          for (int v = 0; v < KV; ++v) {
+            const float4 row = ktab[(size_t)j * KV + v];
 #pragma unroll
-          for (int v = 0; v < KV; ++v) kk[g][v] = s_k[(j + g) * KV + v];
-        }
-        float ma = -3.0e38f, mb = -3.0e38f;
-#pragma unroll
-        for (int g = 0; g < kShadowGroup; ++g) {
-          const float pca = __builtin_fmaf(fa.z, q[g].z, __builtin_fmaf(fa.y, q[g].y, fa.x * q[g].x));
-          const float pcb = __builtin_fmaf(fb.z, q[g].z, __builtin_fmaf(fb.y, q[g].y, fb.x * q[g].x));
-          const float ea = __builtin_fmaf(pca, kTwoKappa, -q[g].w), eb = __builtin_fmaf(pcb, kTwoKappa, -q[g].w);
-          // max_k (h_k^2 + e) = (max_k |h_k|)^2 + e: one subtract and half a max3 per light
-          float ha = 0.0f, hb = 0.0f;
-#pragma unroll
-          for (int k = 0; k < KW; k += 2) {
-            const float k0 = (&kk[g][k / 4].x)[k % 4], k1 = (&kk[g][(k + 1) / 4].x)[(k + 1) % 4];
-            ha = fmaxf(fmaxf(ha, fabsf(fa.P[k] - k0)), fabsf(fa.P[k + 1] - k1));
-            hb = fmaxf(fmaxf(hb, fabsf(fb.P[k] - k0)), fabsf(fb.P[k + 1] - k1));
-          }
-          ma = fmaxf(ma, __builtin_fmaf(ha, ha, ea));
-          mb = fmaxf(mb, __builtin_fmaf(hb, hb, eb));
-        }
-        if (wave_any(ma >= fa.thrp || mb >= fb.thrp)) {
-#pragma unroll 1
-          for (int g = 0; g < kShadowGroup; ++g) {
-            const float4 c = s_f[j + g];
-            const float pca = __builtin_fmaf(fa.z, c.z, __builtin_fmaf(fa.y, c.y, fa.x * c.x));
-            const float pcb = __builtin_fmaf(fb.z, c.z, __builtin_fmaf(fb.y, c.y, fb.x * c.x));
-            const float ea = __builtin_fmaf(pca, kTwoKappa, -c.w), eb = __builtin_fmaf(pcb, kTwoKappa, -c.w);
-            uint32_t mask_a = 0, mask_b = 0;
-#pragma unroll
-            for (int v = 0; v < KV; ++v) {
-              const float4 row = s_k[(j + g) * KV + v];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int k = v * 4 + e;
-                const float kv = (&row.x)[e];
-                const float ha = fa.P[k] - kv, hb = fb.P[k] - kv;
-                if (__builtin_fmaf(ha, ha, ea) >= fa.thrp) mask_a |= 1u << k;
-                if (__builtin_fmaf(hb, hb, eb) >= fb.thrp) mask_b |= 1u << k;
-              }
-            }
-            mask_a &= ~occl_a;
-            mask_b &= ~occl_b;
-            if (wave_any((mask_a | mask_b) != 0)) {
-              const DevObject& ob = S.objects[S.sph_object[base + j + g]];
-              if (mask_a) {
-                const V3 p = load_p(pa);
-                for (uint32_t r = 0; r < nb; ++r)
-                  if ((mask_a >> r) & 1u) {
-                    ++n_exact;
-                    if (shadow_ray_blocked(ob, S.lights[kb + r], p)) occl_a |= 1u << r;
-                  }
-              }
-              if (mask_b) {
-                const V3 p = load_p(pb);
-                for (uint32_t r = 0; r < nb; ++r)
-                  if ((mask_b >> r) & 1u) {
-                    ++n_exact;
-                    if (shadow_ray_blocked(ob, S.lights[kb + r], p)) occl_b |= 1u << r;
-                  }
-              }
+            for (int e = 0; e < 4; ++e) {
+              const int k = v * 4 + e;
+              const float kv = (&row.x)[e];
+              const float ha = fa.P[k] - kv, hb = fb.P[k] - kv;
+              if (__builtin_fmaf(ha, ha, ea) >= fa.thrp) mask_a |= 1u << k;
+              if (__builtin_fmaf(hb, hb, eb) >= fb.thrp) mask_b |= 1u << k;
             }
           }
+          if (!((ma >> bit) & 1ull)) mask_a = 0;
+          if (!((mb >> bit) & 1ull)) mask_b = 0;
+          mask_a &= ~occl_a;
+          mask_b &= ~occl_b;
+          if (wave_any((mask_a | mask_b) != 0)) {
+            const DevObject& ob = S.objects[S.sph_object[j]];
+            if (mask_a) {
+              const V3 p = load_p(pa);
+              for (uint32_t r = 0; r < nb; ++r)
+                if ((mask_a >> r) & 1u) {
+                  ++n_exact;
+                  if (shadow_ray_blocked(ob, S.lights[kb + r], p)) occl_a |= 1u << r;
+                }
+            }
+            if (mask_b) {
+              const V3 p = load_p(pb);
+              for (uint32_t r = 0; r < nb; ++r)
+                if ((mask_b >> r) & 1u) {
+                  ++n_exact;
+                  if (shadow_ray_blocked(ob, S.lights[kb + r], p)) occl_b |= 1u << r;
+                }
+            }
+            changed = true;
+          }
+        }
+        if (changed) {
           // a pixel whose first light is blocked needs nothing more: park it
           if (live_a && (occl_a & 1u)) {
             live_a = false;
@@ -407,7 +481,7 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel
   if (pa.in_range) B.shadow[pa.local] = (uint8_t)((shadow_a ? 0x80u : 0u) | rays_a);
   if (pb.in_range) B.shadow[pb.local] = (uint8_t)((shadow_b ? 0x80u : 0u) | rays_b);
   n_exact = wave_sum(n_exact);
-  if ((threadIdx.x & 63u) == 0) atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
+  if (lane == 0) atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
 }
 
 // Kernel 2b: shadow rays for arbitrary lights (some w != 0): one pixel per lane, per-lane
@@ -498,11 +572,12 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, 
 
 // ------------------------------------------------------------------------------------
 hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
-                                const RenderTarget& T, const OpaqueBuffers& B, DevCounters* counters) {
+                                const float4* prim_ball, const RenderTarget& T, const OpaqueBuffers& B,
+                                DevCounters* counters) {
   if (T.n_local_tiles == 0) return hipSuccess;
   const dim3 pairs((T.n_local_tiles + 1u) / 2u), tiles(T.n_local_tiles), block(kBlock);
   if (S.max_depth > 0) {
-    hipLaunchKernelGGL(primary_kernel, pairs, block, 0, st, S, C, prim, T, B, counters);
+    hipLaunchKernelGGL(primary_kernel, pairs, block, 0, st, S, C, prim, prim_ball, T, B, counters);
     if (S.lights_uniform) {
       if (S.k_width == 4)
         hipLaunchKernelGGL((shadow_uniform_kernel<4>), pairs, block, 0, st, S, C, T, B, counters);

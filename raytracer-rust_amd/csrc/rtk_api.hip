@@ -9,11 +9,13 @@
 #include "rtk_kernels.h"
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -148,6 +150,8 @@ struct rtk_scene_handle {
   float4* d_prim = nullptr;  // primary-ray filter records (rebuilt per camera)
   float4* d_prim_ball = nullptr;  // camera-ray records of the wavefront-level cone test (rebuilt per camera)
   void* d_sph_ball = nullptr;
+  void* d_cluster_ball = nullptr;
+  float4* d_prim_cluster = nullptr;  // camera-ray records of the cluster balls (rebuilt per camera)
   void* d_light_filter = nullptr;
   void* d_k_table = nullptr;
   void* d_sph_tab = nullptr;
@@ -281,10 +285,48 @@ void rtk_scene_release(rtk_context* ctx, rtk_scene_handle* h) {
   if (!h) return;
   if (ctx) (void)hipSetDevice(ctx->device);
   void* ptrs[] = {h->d_objects, h->d_lights, h->d_filter, h->d_exact, h->d_sph_object, h->d_plane_object, h->d_prim,
-                  h->d_light_filter, h->d_k_table, h->d_sph_tab, h->d_prim_ball, h->d_sph_ball};
+                  h->d_light_filter, h->d_k_table, h->d_sph_tab, h->d_prim_ball, h->d_sph_ball, h->d_cluster_ball, h->d_prim_cluster};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
+}
+
+// Reorders the spheres so that every aligned run of kBundle is spatially compact: recursive
+// split along the longest axis of the centres' bounding box, the left part a multiple of
+// kBundle.  Deterministic (ties by original position).
+static void cluster_order(std::vector<double4>& exact, std::vector<uint32_t>& object) {
+  const uint32_t n = (uint32_t)exact.size();
+  if (n <= rtk::kBundle) return;
+  std::vector<uint32_t> idx(n);
+  for (uint32_t i = 0; i < n; ++i) idx[i] = i;
+  std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, n}};
+  while (!todo.empty()) {
+    const auto [lo, hi] = todo.back();
+    todo.pop_back();
+    if (hi - lo <= (uint32_t)rtk::kBundle) continue;
+    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (uint32_t i = lo; i < hi; ++i) {
+      const double c[3] = {exact[idx[i]].x, exact[idx[i]].y, exact[idx[i]].z};
+      for (int a = 0; a < 3; ++a) mn[a] = std::fmin(mn[a], c[a]), mx[a] = std::fmax(mx[a], c[a]);
+    }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+      if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+    const uint32_t groups = (hi - lo + rtk::kBundle - 1) / rtk::kBundle;
+    const uint32_t mid = lo + (groups / 2) * rtk::kBundle;
+    auto key = [&](uint32_t i) { return axis == 0 ? exact[i].x : axis == 1 ? exact[i].y : exact[i].z; };
+    std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, [&](uint32_t p, uint32_t q) {
+      const double kp = key(p), kq = key(q);
+      return kp < kq || (kp == kq && p < q);
+    });
+    todo.push_back({lo, mid});
+    todo.push_back({mid, hi});
+  }
+  std::vector<double4> e2(n);
+  std::vector<uint32_t> o2(n);
+  for (uint32_t i = 0; i < n; ++i) e2[i] = exact[idx[i]], o2[i] = object[idx[i]];
+  exact.swap(e2);
+  object.swap(o2);
 }
 
 int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle** out) {
@@ -346,8 +388,13 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
     lights[k].reserved_ = 0.0;
   }
 
-  // FP32 filter records, recentred on the middle of the sphere centres' bounding box
+  // Sweep order of the spheres: spatial clusters of kBundle (a k-d split down to kBundle
+  // members), so that the wavefront-level tests can skip whole clusters.  Closest-hit ties
+  // are decided by object index (closest_consider), not by sweep order.
   const uint32_t n_sph = (uint32_t)sph_exact.size();
+  cluster_order(sph_exact, sph_object);
+
+  // FP32 filter records, recentred on the middle of the sphere centres' bounding box
   const uint32_t n_pad = round_up_to(n_sph, kBundle);
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   for (uint32_t i = 0; i < n_sph; ++i) {
@@ -389,6 +436,23 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
     }
     const float4 f = filter[j];
     sph_ball[j] = make_float4(f.x, f.y, f.z, round_up(std::sqrt((double)f.w) * (1.0 + 1e-7)));
+  }
+
+  // one ball per cluster of kBundle spheres, around the balls of its members
+  const uint32_t n_clusters = n_pad / kBundle, n_clusters_pad = round_up_to(n_clusters, kBundle);
+  std::vector<float4> cluster_ball(n_clusters_pad, make_float4(0.f, 0.f, 0.f, -1.0e30f));
+  for (uint32_t c = 0; c < n_clusters; ++c) {
+    double m[3] = {0, 0, 0};
+    uint32_t members = 0;
+    for (uint32_t j = c * kBundle; j < std::min((c + 1) * (uint32_t)kBundle, n_sph); ++j, ++members)
+      m[0] += sph_ball[j].x, m[1] += sph_ball[j].y, m[2] += sph_ball[j].z;
+    const float mf[3] = {(float)(m[0] / members), (float)(m[1] / members), (float)(m[2] / members)};
+    double reach = 0.0;
+    for (uint32_t j = c * kBundle; j < c * kBundle + members; ++j) {
+      const double dx = (double)sph_ball[j].x - mf[0], dy = (double)sph_ball[j].y - mf[1], dz = (double)sph_ball[j].z - mf[2];
+      reach = std::fmax(reach, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)sph_ball[j].w);
+    }
+    cluster_ball[c] = make_float4(mf[0], mf[1], mf[2], round_up(reach * (1.0 + 1e-7)));
   }
 
   // Lights with w == 0 (what scene files produce, src/loader.rs:35-40): the shadow-ray line
@@ -456,8 +520,10 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   upload(&h->d_k_table, k_table.data(), k_table.size() * sizeof(float));
   upload(&h->d_sph_tab, sph_tab.data(), sph_tab.size() * sizeof(float4));
   upload(&h->d_sph_ball, sph_ball.data(), sph_ball.size() * sizeof(float4));
+  upload(&h->d_cluster_ball, cluster_ball.data(), cluster_ball.size() * sizeof(float4));
   if (e == hipSuccess && n_pad) e = hipMalloc((void**)&h->d_prim, n_pad * sizeof(float4));
   if (e == hipSuccess && n_pad) e = hipMalloc((void**)&h->d_prim_ball, n_pad * sizeof(float4));
+  if (e == hipSuccess && n_pad) e = hipMalloc((void**)&h->d_prim_cluster, n_clusters_pad * sizeof(float4));
   if (e != hipSuccess) {
     rtk_scene_release(ctx, h);
     return fail_hip(e, "rtk_scene_upload");
@@ -473,6 +539,8 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   d.k_table = (const float4*)h->d_k_table;
   d.sph_tab = (const float4*)h->d_sph_tab;
   d.sph_ball = (const float4*)h->d_sph_ball;
+  d.cluster_ball = (const float4*)h->d_cluster_ball;
+  d.n_clusters_padded = n_clusters_pad;
   d.lights_uniform = lights_uniform ? 1u : 0u;
   d.k_width = k_width;
   d.n_objects = scene->n_objects;
@@ -488,7 +556,6 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   d.r2_max = r2_max;
   d.r_max = r_max;
   d.c_max = c_max;
-  d.pad_ = 0.f;
   *out = h;
   return RTK_OK;
 }
@@ -535,7 +602,7 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
   RTK_HIP(hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   RTK_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, st));
-  RTK_HIP(rtk::launch_prep_primary(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball));
+  RTK_HIP(rtk::launch_prep_primary(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball, scene->d_prim_cluster));
   const bool opaque = !scene->dev.any_secondary;
   if (opaque) {
     // intermediate hit / shadow records: one entry per pixel of this launch
@@ -556,7 +623,7 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
   }
   RTK_HIP(hipEventRecord(ctx->ev_start, st));
   if (opaque)
-    RTK_HIP(rtk::launch_render_opaque(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball, t, ctx->opaque, ctx->d_counters));
+    RTK_HIP(rtk::launch_render_opaque(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball, scene->d_prim_cluster, t, ctx->opaque, ctx->d_counters));
   else
     RTK_HIP(rtk::launch_render(st, scene->dev, cam, scene->d_prim, t, ctx->d_counters));
   RTK_HIP(hipEventRecord(ctx->ev_stop, st));

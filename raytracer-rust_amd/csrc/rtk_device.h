@@ -56,7 +56,9 @@ struct DevScene {
   const float4* k_table;        // [batch][sphere][k_width]: c_j.g_k - R_j'^2 rho_k, only when lights_uniform
   const float4* sph_tab;        // {cx, cy, cz, kappa |c|^2 - R'^2}: sphere record of the tabulated shadow filter
   const float4* sph_ball;       // {cx, cy, cz, R'}: record of the wavefront-level test; padding has R' = -1e30
+  const float4* cluster_ball;   // one ball around each aligned run of kBundle spheres; padded to kBundle with R = -1e30
   uint32_t n_objects, n_lights, n_spheres, n_spheres_padded, n_planes;
+  uint32_t n_clusters_padded;
   uint32_t max_depth;
   uint32_t track_n1;     // some transparent object has refractivity != the others: keep n1
   uint32_t any_secondary; // some material reflects or transmits: rays recurse
@@ -67,7 +69,6 @@ struct DevScene {
   float r2_max;          // max inflated squared radius
   float r_max;           // max inflated radius
   float c_max;           // max |centre - center|
-  float pad_;
 };
 
 struct DevCamera {

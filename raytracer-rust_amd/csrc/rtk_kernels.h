@@ -10,8 +10,9 @@ namespace rtk {
 int light_batch_for(uint32_t n_lights);
 
 // Rebuilds the camera-ray records for camera C: prim[n_spheres_padded] (per-ray filter) and
-// prim_ball[n_spheres_padded] (wavefront-level cone test).
-hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamera& C, float4* prim, float4* prim_ball);
+// prim_ball[n_spheres_padded] and prim_cluster[n_clusters_padded] (wavefront-level cone tests).
+hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamera& C, float4* prim, float4* prim_ball,
+                               float4* prim_cluster);
 
 // Renders the tiles selected by T.
 hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim, const RenderTarget& T,
@@ -20,7 +21,8 @@ hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, 
 // Same for scenes without reflective or transparent materials: three lean kernels
 // (camera rays, shadow rays, shading) with intermediate records in B.
 hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
-                                const float4* prim_ball, const RenderTarget& T, const OpaqueBuffers& B,
+                                const float4* prim_ball, const float4* prim_cluster, const RenderTarget& T,
+                                const OpaqueBuffers& B,
                                 DevCounters* counters);
 
 // Traces n caller-supplied rays (device pointers, n x 4 doubles in, n x 3 doubles out).

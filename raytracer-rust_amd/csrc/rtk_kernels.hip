@@ -270,15 +270,26 @@ __global__ void __launch_bounds__(kBlock) trace_rays_kernel(DevScene S, const do
 
 // Per-camera records of the camera-ray tests: one thread per (padded) sphere.
 __global__ void __launch_bounds__(kBlock) prep_primary_kernel(DevScene S, DevCamera C, float4* __restrict__ prim,
-                                                              float4* __restrict__ prim_ball) {
+                                                              float4* __restrict__ prim_ball,
+                                                              float4* __restrict__ prim_cluster) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const double eps = (double)kEps32;
+  if (prim_cluster && i < S.n_clusters_padded) {
+    // cluster ball as seen from the camera; the ball already contains its members' balls
+    const float4 cb = S.cluster_ball[i];
+    const double Lx = (double)cb.x + S.center[0] - C.origin[0], Ly = (double)cb.y + S.center[1] - C.origin[1],
+                 Lz = (double)cb.z + S.center[2] - C.origin[2];
+    const double Rs = (double)cb.w * (1.0 + 1e-6) + 16.0 * eps * sqrt(Lx * Lx + Ly * Ly + Lz * Lz);
+    float rsf = (float)Rs;
+    if ((double)rsf < Rs) rsf = nextafterf(rsf, INFINITY);
+    prim_cluster[i] = cb.w >= 0.0f ? make_float4((float)Lx, (float)Ly, (float)Lz, rsf) : make_float4(0.f, 0.f, 0.f, -1.0f);
+  }
   if (i >= S.n_spheres_padded) return;
   // padding of the per-ray records repeats the last real sphere (see rtk_scene_upload);
   // padding of the wavefront-level records can never pass (negative radius)
   const double4 s = S.sph_exact[min(i, S.n_spheres - 1u)];
   const double Lx = s.x - C.origin[0], Ly = s.y - C.origin[1], Lz = s.z - C.origin[2];
   const double LL = Lx * Lx + Ly * Ly + Lz * Lz;
-  const double eps = (double)kEps32;
   // rounding L to FP32 moves the centre by at most eps|L|: grow the ball by that much
   const double R = s.w * (1.0 + 1e-12) + 1.01 * eps * sqrt(LL);
   // 12 eps |L|^2 covers the dot product (3 roundings), the rounded direction and this record's own rounding
@@ -342,10 +353,12 @@ int light_batch_for(uint32_t n_lights) {
   return 8;
 }
 
-hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamera& C, float4* prim, float4* prim_ball) {
+hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamera& C, float4* prim, float4* prim_ball,
+                               float4* prim_cluster) {
   if (S.n_spheres_padded == 0) return hipSuccess;
+  // n_clusters_padded <= n_spheres_padded: one grid covers both record arrays
   dim3 grid((S.n_spheres_padded + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(prep_primary_kernel, grid, dim3(kBlock), 0, st, S, C, prim, prim_ball);
+  hipLaunchKernelGGL(prep_primary_kernel, grid, dim3(kBlock), 0, st, S, C, prim, prim_ball, prim_cluster);
   return hipGetLastError();
 }
 

@@ -108,9 +108,9 @@ __device__ __forceinline__ bool cone_reaches(const Cone& c, float4 ball) {
 // Kernel 1: camera rays.  Workgroup b owns local tiles 2b' and 2b'+1 (bottom of the frame
 // first); each lane traces the same slot of both tiles, each wavefront two 8x8 patches.
 __global__ void __launch_bounds__(kBlock, 8) primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
-                                                           const float4* __restrict__ prim_ball, RenderTarget T,
+                                                           const float4* __restrict__ prim_ball,
+                                                           const float4* __restrict__ prim_cluster, RenderTarget T,
                                                            OpaqueBuffers B, DevCounters* counters) {
-  __shared__ float4 s_buf[kChunk];
   const uint32_t pairs = (T.n_local_tiles + 1u) / 2u;
   const uint32_t pr = pairs - 1u - blockIdx.x;
   const PixelRef pa = pixel_ref(T, C, 2u * pr), pb = pixel_ref(T, C, 2u * pr + 1u);
@@ -137,45 +137,50 @@ __global__ void __launch_bounds__(kBlock, 8) primary_kernel(DevScene S, DevCamer
   const Cone cone_a = make_cone(ax, ay, az), cone_b = make_cone(bx, by, bz);
   const bool live_a = wave_any(pa.valid), live_b = wave_any(pb.valid);
 
-  for (uint32_t base = 0; base < S.n_spheres_padded; base += kChunk) {
-    const uint32_t count = min((uint32_t)kChunk, S.n_spheres_padded - base);
-    stage_chunk(s_buf, prim_ball, base, count);
-    if (!(live_a || live_b)) continue;
-    for (uint32_t blk = 0; blk < count; blk += 64u) {
-      // level 1: this lane's sphere against both cones
-      const float4 ball = s_buf[blk + lane];
-      const unsigned long long ma = live_a ? __builtin_amdgcn_ballot_w64(cone_reaches(cone_a, ball)) : 0ull;
-      const unsigned long long mb = live_b ? __builtin_amdgcn_ballot_w64(cone_reaches(cone_b, ball)) : 0ull;
-      // level 2: per-ray filter and exact test for the spheres level 1 kept
-      for (unsigned long long m = ma | mb; m != 0ull; m &= m - 1ull) {
-        const uint32_t bit = (uint32_t)__builtin_ctzll(m);
-        const uint32_t j = base + blk + bit;
-        const float4 r = prim[j];
-        float ta = r.x * ax;
-        ta = __builtin_fmaf(r.y, ay, ta);
-        ta = __builtin_fmaf(r.z, az, ta);
-        float tb = r.x * bx;
-        tb = __builtin_fmaf(r.y, by, tb);
-        tb = __builtin_fmaf(r.z, bz, tb);
-        const bool pass_a = pa.valid && ((ma >> bit) & 1ull) && __builtin_fmaf(ta, ta, -r.w) >= 0.0f;
-        const bool pass_b = pb.valid && ((mb >> bit) & 1ull) && __builtin_fmaf(tb, tb, -r.w) >= 0.0f;
-        if (wave_any(pass_a || pass_b)) {
-          const uint32_t obj = S.sph_object[j];
-          double t0, t1;
-          if (pass_a) {
-            ++n_exact;
-            const V3 d = camera_ray_direction(C, launder(pa.x), pa.y);
-            if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
-              closest_consider(best_a, t0, obj, false);
-              closest_consider(best_a, t1, obj, false);
+  if (live_a || live_b) {
+    for (uint32_t cbase = 0; cbase < S.n_clusters_padded; cbase += kBundle) {
+      // level 0: this lane's cluster against both cones
+      const float4 cl = prim_cluster[cbase + lane];
+      const unsigned long long ca = live_a ? __builtin_amdgcn_ballot_w64(cone_reaches(cone_a, cl)) : 0ull;
+      const unsigned long long cb = live_b ? __builtin_amdgcn_ballot_w64(cone_reaches(cone_b, cl)) : 0ull;
+      for (unsigned long long cm = ca | cb; cm != 0ull; cm &= cm - 1ull) {
+        const uint32_t cbit = (uint32_t)__builtin_ctzll(cm);
+        const uint32_t first = (cbase + cbit) * kBundle;
+        // level 1: this lane's sphere of the cluster against the cones that reach the cluster
+        const float4 ball = prim_ball[first + lane];
+        const unsigned long long ma = ((ca >> cbit) & 1ull) ? __builtin_amdgcn_ballot_w64(cone_reaches(cone_a, ball)) : 0ull;
+        const unsigned long long mb = ((cb >> cbit) & 1ull) ? __builtin_amdgcn_ballot_w64(cone_reaches(cone_b, ball)) : 0ull;
+        // level 2: per-ray filter and exact test for the spheres level 1 kept
+        for (unsigned long long m = ma | mb; m != 0ull; m &= m - 1ull) {
+          const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+          const uint32_t j = first + bit;
+          const float4 r = prim[j];
+          float ta = r.x * ax;
+          ta = __builtin_fmaf(r.y, ay, ta);
+          ta = __builtin_fmaf(r.z, az, ta);
+          float tb = r.x * bx;
+          tb = __builtin_fmaf(r.y, by, tb);
+          tb = __builtin_fmaf(r.z, bz, tb);
+          const bool pass_a = pa.valid && ((ma >> bit) & 1ull) && __builtin_fmaf(ta, ta, -r.w) >= 0.0f;
+          const bool pass_b = pb.valid && ((mb >> bit) & 1ull) && __builtin_fmaf(tb, tb, -r.w) >= 0.0f;
+          if (wave_any(pass_a || pass_b)) {
+            const uint32_t obj = S.sph_object[j];
+            double t0, t1;
+            if (pass_a) {
+              ++n_exact;
+              const V3 d = camera_ray_direction(C, launder(pa.x), pa.y);
+              if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
+                closest_consider(best_a, t0, obj, false);
+                closest_consider(best_a, t1, obj, false);
+              }
             }
-          }
-          if (pass_b) {
-            ++n_exact;
-            const V3 d = camera_ray_direction(C, launder(pb.x), pb.y);
-            if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
-              closest_consider(best_b, t0, obj, false);
-              closest_consider(best_b, t1, obj, false);
+            if (pass_b) {
+              ++n_exact;
+              const V3 d = camera_ray_direction(C, launder(pb.x), pb.y);
+              if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
+                closest_consider(best_b, t0, obj, false);
+                closest_consider(best_b, t1, obj, false);
+              }
             }
           }
         }
@@ -298,7 +303,6 @@ template <int KW>
 __global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel(DevScene S, DevCamera C, RenderTarget T,
                                                                                 OpaqueBuffers B, DevCounters* counters) {
   constexpr int KV = KW / 4;  // float4 per table row
-  __shared__ float4 s_buf[kChunk];
   const uint32_t pairs = (T.n_local_tiles + 1u) / 2u;
   const uint32_t pr = pairs - 1u - blockIdx.x;
   const PixelRef pa = pixel_ref(T, C, 2u * pr), pb = pixel_ref(T, C, 2u * pr + 1u);
@@ -328,7 +332,7 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel
   bool shadow_a = false, shadow_b = false;
 
   for (uint32_t kb = 0, batch = 0; kb < S.n_lights; kb += KW, ++batch) {
-    if (!__syncthreads_or(need_a || need_b)) break;
+    if (!wave_any(need_a || need_b)) break;
     const uint32_t nb = min((uint32_t)KW, S.n_lights - kb);
     uint32_t occl_a = 0, occl_b = 0;
     PixelFilter<KW> fa, fb;
@@ -368,37 +372,47 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel
     const float pad_b = ball_b.radius + grow * 1.01f +
                         16.0f * kEps32 * (fabsf(ball_b.mx) + fabsf(ball_b.my) + fabsf(ball_b.mz) + ball_b.radius + S.c_max);
 
-    auto lines_reach = [&](const Ball& bl, float pad, float4 rec) {
+    // rec = {centre, radius} of a sphere (t_extra = 0, growth radius = its own) or of a
+    // cluster (t_extra = its radius, growth radius = the scene's largest sphere radius)
+    auto lines_reach = [&](const Ball& bl, float pad, float4 rec, float t_extra, float r_grow) {
       const float ux = bl.mx - rec.x, uy = bl.my - rec.y, uz = bl.mz - rec.z;
-      const float reach = rec.w + pad;  // R' + rho_w + slack
+      const float reach = rec.w + pad;  // R + rho_w + slack
+      const float tb = bl.radius + t_extra;
       bool pass = false;
 #pragma unroll
       for (int k = 0; k < KW; ++k) {
         const float s = __builtin_fmaf(uz, lgz[k], __builtin_fmaf(uy, lgy[k], ux * lgx[k]));
         const float qx = __builtin_fmaf(-s, lgx[k], ux), qy = __builtin_fmaf(-s, lgy[k], uy), qz = __builtin_fmaf(-s, lgz[k], uz);
         const float d2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
-        const float t = fmaxf(bl.radius - s, 0.0f);
-        const float rr = __builtin_fmaf(t, rec.w * lrho[k], reach) * (1.0f + 4.0f * kEps32);
+        const float t = fmaxf(tb - s, 0.0f) * (1.0f + 8.0f * kEps32);
+        const float rr = __builtin_fmaf(t, r_grow * lrho[k], reach) * (1.0f + 4.0f * kEps32);
         pass |= rr >= 0.0f && __builtin_fmaf(rr, rr, -d2) >= 0.0f;
       }
       return pass;
     };
 
     bool wave_live = wave_any(live_a || live_b);
-    for (uint32_t base = 0; base < S.n_spheres_padded; base += kChunk) {
-      const uint32_t count = min((uint32_t)kChunk, S.n_spheres_padded - base);
-      stage_chunk(s_buf, S.sph_ball, base, count);
-      if (!wave_live) continue;
-      for (uint32_t blk = 0; blk < count; blk += 64u) {
-        // level 1: this lane's sphere against the line bundles of both patches
-        const float4 rec = s_buf[blk + lane];
-        const unsigned long long ma = wave_any(live_a) ? __builtin_amdgcn_ballot_w64(lines_reach(ball_a, pad_a, rec)) : 0ull;
-        const unsigned long long mb = wave_any(live_b) ? __builtin_amdgcn_ballot_w64(lines_reach(ball_b, pad_b, rec)) : 0ull;
+    for (uint32_t cbase = 0; wave_live && cbase < S.n_clusters_padded; cbase += kBundle) {
+      // level 0: this lane's cluster against the line bundles of both patches
+      const float4 cl = S.cluster_ball[cbase + lane];
+      const unsigned long long ca =
+          wave_any(live_a) ? __builtin_amdgcn_ballot_w64(lines_reach(ball_a, pad_a, cl, cl.w, S.r_max)) : 0ull;
+      const unsigned long long cb =
+          wave_any(live_b) ? __builtin_amdgcn_ballot_w64(lines_reach(ball_b, pad_b, cl, cl.w, S.r_max)) : 0ull;
+      for (unsigned long long cm = ca | cb; wave_live && cm != 0ull; cm &= cm - 1ull) {
+        const uint32_t cbit = (uint32_t)__builtin_ctzll(cm);
+        const uint32_t first = (cbase + cbit) * kBundle;
+        // level 1: this lane's sphere of the cluster
+        const float4 rec = S.sph_ball[first + lane];
+        const unsigned long long ma =
+            ((ca >> cbit) & 1ull) && wave_any(live_a) ? __builtin_amdgcn_ballot_w64(lines_reach(ball_a, pad_a, rec, 0.0f, rec.w)) : 0ull;
+        const unsigned long long mb =
+            ((cb >> cbit) & 1ull) && wave_any(live_b) ? __builtin_amdgcn_ballot_w64(lines_reach(ball_b, pad_b, rec, 0.0f, rec.w)) : 0ull;
         bool changed = false;
         // level 2: per-ray tabulated filter, then the exact test
         for (unsigned long long m = ma | mb; m != 0ull; m &= m - 1ull) {
           const uint32_t bit = (uint32_t)__builtin_ctzll(m);
-          const uint32_t j = base + blk + bit;
+          const uint32_t j = first + bit;
           const float4 c = S.sph_tab[j];
           const float pca = __builtin_fmaf(fa.z, c.z, __builtin_fmaf(fa.y, c.y, fa.x * c.x));
           const float pcb = __builtin_fmaf(fb.z, c.z, __builtin_fmaf(fb.y, c.y, fb.x * c.x));
@@ -452,7 +466,6 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel
             park(fb);
           }
           wave_live = wave_any(live_a || live_b);
-          if (!wave_live) break;
         }
       }
     }
@@ -572,12 +585,12 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, 
 
 // ------------------------------------------------------------------------------------
 hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
-                                const float4* prim_ball, const RenderTarget& T, const OpaqueBuffers& B,
-                                DevCounters* counters) {
+                                const float4* prim_ball, const float4* prim_cluster, const RenderTarget& T,
+                                const OpaqueBuffers& B, DevCounters* counters) {
   if (T.n_local_tiles == 0) return hipSuccess;
   const dim3 pairs((T.n_local_tiles + 1u) / 2u), tiles(T.n_local_tiles), block(kBlock);
   if (S.max_depth > 0) {
-    hipLaunchKernelGGL(primary_kernel, pairs, block, 0, st, S, C, prim, prim_ball, T, B, counters);
+    hipLaunchKernelGGL(primary_kernel, pairs, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);
     if (S.lights_uniform) {
       if (S.k_width == 4)
         hipLaunchKernelGGL((shadow_uniform_kernel<4>), pairs, block, 0, st, S, C, T, B, counters);

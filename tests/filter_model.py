@@ -143,3 +143,93 @@ class FilterScene:
         e = fma(pcd, two_kappa, -ccf)
         h = (P - K).astype(F)
         return fma(h, h, e) >= thrp
+
+
+# ---- wavefront-level tests (one sphere or cluster per lane against a bundle of 64 rays) -------
+
+def cluster_balls(cf, ball_r, bundle=64):
+    """Cluster records of rtk_scene_upload: mean centre and reach over aligned runs of `bundle`."""
+    out = []
+    for lo in range(0, len(cf), bundle):
+        c, r = cf[lo:lo + bundle].astype(np.float64), ball_r[lo:lo + bundle].astype(np.float64)
+        mf = c.mean(axis=0).astype(F)
+        reach = (np.sqrt(((c - mf.astype(np.float64)) ** 2).sum(axis=1)) + r).max()
+        out.append([mf[0], mf[1], mf[2], round_up(reach * (1.0 + 1e-7))])
+    return np.array(out, dtype=F)
+
+
+def sphere_balls(fs):
+    """sph_ball records: recentred centre and the inflated radius, not squared."""
+    return np.concatenate([fs.cf, round_up(np.sqrt(fs.r2.astype(np.float64)) * (1.0 + 1e-7))[:, None]], axis=1).astype(F)
+
+
+def camera_records(L, radius):
+    """prim_ball / prim_cluster records of prep_primary_kernel for balls at L (f64, relative to the
+    camera origin) with the given radius."""
+    Rs = radius * (1.0 + 1e-6) + 16.0 * float(EPS32) * np.sqrt((L * L).sum(axis=1))
+    return np.concatenate([L.astype(F), round_up(Rs)[:, None]], axis=1).astype(F)
+
+
+def make_cone(d):
+    """make_cone of csrc/rtk_opaque.hip for the FP32 directions d [64, 3] of one patch."""
+    d = d.astype(F)
+    s = d.sum(axis=0, dtype=F)
+    inv = F(1.0) / np.sqrt(F(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]))
+    a = (s * inv).astype(F)
+    along = (d[:, 0] * a[0] + d[:, 1] * a[1] + d[:, 2] * a[2]).astype(F)
+    q = (d - along[:, None] * a[None, :]).astype(F)
+    across = np.sqrt((q * q).sum(axis=1, dtype=F)).astype(F)
+    t = np.where(along > 0, across / np.where(along > 0, along, F(1)), F(3.0e38)).astype(F)
+    tan_t = F(t.max() * F(1.0 + 1.0e-5) + F(2.0e-6))
+    sec_t = F(np.sqrt(F(1.0) + tan_t * tan_t) * F(1.0 + 1.0e-6))
+    return a, tan_t, sec_t
+
+
+def cone_reaches(cone, ball):
+    a, tan_t, sec_t = cone
+    s = fma(ball[:, 2], a[2], fma(ball[:, 1], a[1], (ball[:, 0] * a[0]).astype(F)))
+    qx, qy, qz = fma(-s, a[0], ball[:, 0]), fma(-s, a[1], ball[:, 1]), fma(-s, a[2], ball[:, 2])
+    d2 = fma(qz, qz, fma(qy, qy, (qx * qx).astype(F)))
+    rr = fma(s, tan_t, (ball[:, 3] * sec_t).astype(F))
+    return (rr >= 0) & (fma(rr, rr, -d2) >= 0)
+
+
+def make_ball(pts):
+    """make_ball: mean and radius of the FP32 recentred shading points [n, 3] of one patch."""
+    pts = pts.astype(F)
+    n = F(len(pts))
+    inv = F(1.0) / n
+    m = (pts.sum(axis=0, dtype=F) * inv).astype(F)
+    e = (pts - m).astype(F)
+    far = np.sqrt((e * e).sum(axis=1, dtype=F)).astype(F)
+    return m, F(far.max() * F(1.0 + 1.0e-5))
+
+
+def lines_reach(fs, ball, lights_xyz, rec, cluster):
+    """lines_reach of shadow_uniform_kernel: ball = make_ball(...), rec [n, 4] sphere or cluster
+    records; True where some light's line bundle may touch the record's ball."""
+    m, radius = ball
+    Lv = np.asarray(lights_xyz, np.float64).reshape(-1, 3)
+    inv = 1.0 / np.sqrt((Lv * Lv).sum(axis=1))
+    g = (Lv * inv[:, None]).astype(F)
+    rho = (-inv).astype(F)
+    lrho = (np.abs(rho) * F(1.0001)).astype(F)
+    grow = F(0)
+    for k in range(len(Lv)):
+        grow = max(grow, F(F(0.5) * fs.r_max * fs.r2_max * rho[k] * rho[k]))
+    pad = F(radius + grow * F(1.01) +
+            F(16.0) * EPS32 * (abs(m[0]) + abs(m[1]) + abs(m[2]) + radius + fs.c_max))
+    t_extra = rec[:, 3] if cluster else F(0)
+    r_grow = fs.r_max if cluster else rec[:, 3]
+    ux, uy, uz = (m[0] - rec[:, 0]).astype(F), (m[1] - rec[:, 1]).astype(F), (m[2] - rec[:, 2]).astype(F)
+    reach = (rec[:, 3] + pad).astype(F)
+    tb = (radius + t_extra).astype(F) if cluster else F(radius)
+    ok = np.zeros(len(rec), bool)
+    for k in range(len(Lv)):
+        s = fma(uz, g[k, 2], fma(uy, g[k, 1], (ux * g[k, 0]).astype(F)))
+        qx, qy, qz = fma(-s, g[k, 0], ux), fma(-s, g[k, 1], uy), fma(-s, g[k, 2], uz)
+        d2 = fma(qz, qz, fma(qy, qy, (qx * qx).astype(F)))
+        t = (np.maximum((tb - s).astype(F), F(0)) * F(1.0 + 8.0 * float(EPS32))).astype(F)
+        rr = (fma(t, (r_grow * lrho[k]).astype(F), reach) * F(1.0 + 4.0 * float(EPS32))).astype(F)
+        ok |= (rr >= 0) & (fma(rr, rr, -d2) >= 0)
+    return ok

@@ -178,3 +178,92 @@ def test_filter_stays_selective_on_a_c4_like_scene(rtk):
 def fs_rows(fs, point, light, n):
     """Tabulated filter of one shading point against all n spheres."""
     return fs.tabulated_pass(np.broadcast_to(point, (n, 3)), light)
+
+
+# ---- wavefront-level tests -------------------------------------------------------------------
+from filter_model import (camera_records, cluster_balls, cone_reaches, lines_reach, make_ball, make_cone,
+                          sphere_balls)
+
+
+@pytest.mark.parametrize("scale", [3.0, 60.0, 1500.0])
+def test_cone_test_keeps_every_sphere_some_ray_of_the_patch_grazes(scale):
+    """64 camera rays of an 8x8 patch; 64 spheres, sphere i only just touched by ray i.  Neither
+    the sphere-level nor the cluster-level cone test may drop one."""
+    rng = np.random.default_rng(int(scale) + 11)
+    for trial in range(60):
+        origin = rng.normal(size=3) * scale * 0.3
+        axis = _unit(rng.normal(size=3))
+        e1 = _unit(np.cross(axis, rng.normal(size=3)))
+        e2 = np.cross(axis, e1)
+        ps = 10.0 ** rng.uniform(-4.5, -1.5)  # pixel pitch on the image plane
+        off = rng.uniform(-0.8, 0.8, size=2)
+        gx, gy = np.meshgrid(np.arange(8) - 3.5, np.arange(8) - 3.5)
+        d = _unit(axis + e1 * (off[0] + gx.reshape(-1, 1) * ps) + e2 * (off[1] + gy.reshape(-1, 1) * ps))
+        n = 64
+        dist = scale * rng.uniform(0.02, 1.0, size=(n, 1))
+        perp = _unit(np.cross(d, rng.normal(size=(n, 3))))
+        c = origin + d * dist + perp * rng.uniform(0.01, 2.0, size=(n, 1))
+        p = np.broadcast_to(origin, (n, 3))
+        Rstar = grazing_radius(p, d, np.zeros(n), c)
+        cone = make_cone(d.astype(np.float32))
+        for delta in (1e-13, 1e-8, 1e-3):
+            R = Rstar * (1.0 + delta)
+            hit = exact_disc(p, d, np.zeros(n), c, R) >= 0
+            fs = FilterScene(c, R)
+            spheres = camera_records(c - origin, R)
+            assert not (hit & ~cone_reaches(cone, spheres)).any(), (trial, delta)
+            balls = sphere_balls(fs)
+            cl = cluster_balls(balls[:, :3], balls[:, 3])
+            Lc = cl[:, :3].astype(np.float64) + fs.center - origin
+            assert cone_reaches(cone, camera_records(Lc, cl[:, 3].astype(np.float64))).all() or not hit.any()
+
+
+@pytest.mark.parametrize("scale", [3.0, 60.0, 1500.0])
+def test_line_bundle_test_keeps_every_sphere_some_shadow_ray_of_the_patch_grazes(scale):
+    rng = np.random.default_rng(int(scale) + 23)
+    for trial in range(60):
+        n = 64
+        centre = rng.normal(size=3) * scale * 0.4
+        pts = centre + rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-3, 0.3)
+        nl = int(rng.integers(1, 5))
+        lights = np.array([0.3, 1.0, -0.2]) * scale * rng.uniform(0.3, 3.0) + rng.normal(size=(nl, 3)) * scale * 0.3
+        k = rng.integers(0, nl, size=n)
+        L = lights[k]
+        lv = L - pts
+        m = np.sqrt((lv * lv).sum(axis=1) + 1.0)
+        d, dw = lv / m[:, None], -1.0 / m
+        s = rng.uniform(-0.5, 1.5, size=(n, 1))
+        c = pts + lv * s + rng.normal(size=(n, 3)) * rng.uniform(0.01, 3.0, size=(n, 1))
+        Rstar = grazing_radius(pts, d, dw, c)
+        for delta in (1e-13, 1e-8, 1e-3):
+            R = Rstar * (1.0 + delta)
+            hit = exact_disc(pts, d, dw, c, R) >= 0
+            fs = FilterScene(c, R)
+            ball = make_ball((pts - fs.center).astype(np.float32))
+            balls = sphere_balls(fs)
+            assert not (hit & ~lines_reach(fs, ball, lights, balls, cluster=False)).any(), (trial, delta)
+            cl = cluster_balls(balls[:, :3], balls[:, 3])
+            assert lines_reach(fs, ball, lights, cl, cluster=True).all() or not hit.any()
+
+
+def test_bundle_tests_stay_selective_on_a_c4_like_scene(rtk):
+    """Regression guard for speed: an 8x8 patch looking at the 10k-sphere field keeps few clusters."""
+    scene, camera = rtk.synthetic.config("C4", 3840, 2160)
+    spheres = [n for n in scene.nodes if n.kind == rtk.abi.RTK_SPHERE]
+    c = np.array([[n.transform.e[3], n.transform.e[7], n.transform.e[11]] for n in spheres])
+    R = np.array([n.transform.e[0] for n in spheres])
+    inv = np.linalg.inv(np.array(camera.transform.e).reshape(4, 4))
+    origin = inv[:3, 3]
+    gx, gy = np.meshgrid(np.arange(8), np.arange(8))
+    kept = []
+    for x0, y0 in ((1900, 1500), (600, 1900), (3000, 1200)):
+        xs, ys = (x0 + gx).reshape(-1) + 0.5, (y0 + gy).reshape(-1) + 0.5
+        px = np.stack([camera.half_width - xs * camera.pixel_size, camera.half_height - ys * camera.pixel_size,
+                       -np.ones(64), np.ones(64)], axis=1)
+        d = _unit((inv @ px.T).T[:, :3] - origin)
+        keep = cone_reaches(make_cone(d.astype(np.float32)), camera_records(c - origin, R))
+        hit = np.stack([exact_disc(np.broadcast_to(origin, (len(c), 3)), np.broadcast_to(di, (len(c), 3)),
+                                   np.zeros(len(c)), c, R) >= 0 for di in d]).any(axis=0)
+        assert not (hit & ~keep).any()
+        kept.append(int(keep.sum()))
+    assert max(kept) <= 64, kept

@@ -547,6 +547,7 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   d.n_lights = scene->n_lights;
   d.n_spheres = n_sph;
   d.n_spheres_padded = n_pad;
+  d.n_spheres_grouped = round_up_to(n_sph, kGroup);
   d.n_planes = (uint32_t)plane_object.size();
   d.max_depth = scene->max_depth;
   d.track_n1 = track_n1 ? 1u : 0u;

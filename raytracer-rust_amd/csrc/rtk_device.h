@@ -43,8 +43,9 @@ struct DevLight {
 //   w       : inflated squared radius (covers centre rounding), rounded up
 // Record of the primary-ray filter (rebuilt per camera by prep_primary_kernel):
 //   x, y, z : centre minus camera origin;  w : |L|^2 (1 - slack) - R'^2, rounded down
-// Both arrays (and sph_object) are padded to a multiple of kGroup by repeating the last
-// real record; testing a sphere twice changes no decision.
+// Both arrays (and sph_object) are padded to a multiple of kBundle by repeating the last
+// real record; testing a sphere twice changes no decision.  The one-ray-per-lane sweeps stop
+// at n_spheres_grouped.
 struct DevScene {
   const DevObject* objects;
   const DevLight* lights;
@@ -59,6 +60,7 @@ struct DevScene {
   const float4* cluster_ball;   // one ball around each aligned run of kBundle spheres; padded to kBundle with R = -1e30
   uint32_t n_objects, n_lights, n_spheres, n_spheres_padded, n_planes;
   uint32_t n_clusters_padded;
+  uint32_t n_spheres_grouped;  // n_spheres rounded up to kGroup: what the one-ray-per-lane sweeps cover
   uint32_t max_depth;
   uint32_t track_n1;     // some transparent object has refractivity != the others: keep n1
   uint32_t any_secondary; // some material reflects or transmits: rays recurse

@@ -107,7 +107,7 @@ __device__ __forceinline__ bool cone_reaches(const Cone& c, float4 ball) {
 // ------------------------------------------------------------------------------------
 // Kernel 1: camera rays.  Workgroup b owns local tiles 2b' and 2b'+1 (bottom of the frame
 // first); each lane traces the same slot of both tiles, each wavefront two 8x8 patches.
-__global__ void __launch_bounds__(kBlock, 8) primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
+__global__ void __launch_bounds__(kBlock, 4) primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                            const float4* __restrict__ prim_ball,
                                                            const float4* __restrict__ prim_cluster, RenderTarget T,
                                                            OpaqueBuffers B, DevCounters* counters) {
@@ -300,7 +300,7 @@ __device__ __forceinline__ Ball make_ball(bool live, float x, float y, float z) 
 // ball, see PixelFilter).  Over the ball of points: distance(c, line through m) <=
 // rho_w + R + R |rho| max(rho_w - s_m, 0) + R^3 rho^2 / 2.
 template <int KW>
-__global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel(DevScene S, DevCamera C, RenderTarget T,
+__global__ void __launch_bounds__(kBlock, KW == 4 ? 4 : 3) shadow_uniform_kernel(DevScene S, DevCamera C, RenderTarget T,
                                                                                 OpaqueBuffers B, DevCounters* counters) {
   constexpr int KV = KW / 4;  // float4 per table row
   const uint32_t pairs = (T.n_local_tiles + 1u) / 2u;
@@ -331,6 +331,9 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel
   unsigned rays_a = 0, rays_b = 0, n_exact = 0;
   bool shadow_a = false, shadow_b = false;
 
+#if RTK_EXP == 1
+  need_a = need_b = false;
+#endif
   for (uint32_t kb = 0, batch = 0; kb < S.n_lights; kb += KW, ++batch) {
     if (!wave_any(need_a || need_b)) break;
     const uint32_t nb = min((uint32_t)KW, S.n_lights - kb);
@@ -343,7 +346,9 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel
       const V3 p = load_p(pa);
       for (uint32_t r = 0; r < nb; ++r)
         for (uint32_t ip = 0; ip < S.n_planes; ++ip)
-          if (shadow_ray_blocked(S.objects[S.plane_object[ip]], S.lights[kb + r], p)) occl_a |= 1u << r;
+          if (plane_may_block(S.objects[S.plane_object[ip]], S.lights[kb + r], p) &&
+              shadow_ray_blocked(S.objects[S.plane_object[ip]], S.lights[kb + r], p))
+            occl_a |= 1u << r;
       live_a = !(occl_a & 1u);
       if (live_a) arm(fa, S, p, kb, nb);
     }
@@ -351,7 +356,9 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel
       const V3 p = load_p(pb);
       for (uint32_t r = 0; r < nb; ++r)
         for (uint32_t ip = 0; ip < S.n_planes; ++ip)
-          if (shadow_ray_blocked(S.objects[S.plane_object[ip]], S.lights[kb + r], p)) occl_b |= 1u << r;
+          if (plane_may_block(S.objects[S.plane_object[ip]], S.lights[kb + r], p) &&
+              shadow_ray_blocked(S.objects[S.plane_object[ip]], S.lights[kb + r], p))
+            occl_b |= 1u << r;
       live_b = !(occl_b & 1u);
       if (live_b) arm(fb, S, p, kb, nb);
     }
@@ -392,6 +399,9 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 6 : 5) shadow_uniform_kernel
     };
 
     bool wave_live = wave_any(live_a || live_b);
+#if RTK_EXP == 2
+    wave_live = false;
+#endif
     for (uint32_t cbase = 0; wave_live && cbase < S.n_clusters_padded; cbase += kBundle) {
       // level 0: this lane's cluster against the line bundles of both patches
       const float4 cl = S.cluster_ball[cbase + lane];

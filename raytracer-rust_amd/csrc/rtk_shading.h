@@ -69,6 +69,26 @@ __device__ __forceinline__ int intersect_object(const DevObject& ob, V3 o, V3 d,
   return 0;
 }
 
+// Can the reference's shadow ray from p towards light L meet the plane `ob` at a positive
+// parameter?  `Plane::intersect` (src/scene/shapes/planes.rs:22-28) returns
+// t = -o'.y / d'.y for the object-space origin o' and direction d' = inverse * (L - p)/m.
+// o'.y is formed here exactly as intersect_object forms it.  d'.y has the sign of the same
+// row applied to the unnormalised L - p as long as that sum is clear of its rounding error
+// (|d'.y m - g| <= 6 ulp of the sum of the terms' magnitudes).  When o'.y and d'.y share a
+// sign, t < 0, and when o'.y == 0, t == 0: `is_shadowed` (src/scene.rs:208-225) wants
+// t > 0 either way, so the square root and the divisions can be skipped.  Returns false only then.
+__device__ __forceinline__ bool plane_may_block(const DevObject& ob, const DevLight& L, V3 p) {
+  const double* m = ob.inv;
+  const double oy = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+  const double a = m[4] * (L.pos[0] - p.x), b = m[5] * (L.pos[1] - p.y), c = m[6] * (L.pos[2] - p.z), d = m[7] * (L.pos[3] - 1.0);
+  const double g = a + b + c + d;
+  const double noise = 1.0e-12 * (fabs(a) + fabs(b) + fabs(c) + fabs(d));
+  if (oy == 0.0) return false;
+  if (oy > 0.0 && g > noise) return false;
+  if (oy < 0.0 && g < -noise) return false;
+  return true;
+}
+
 // Closest-hit bookkeeping.  The reference sorts all hits stably by distance and takes the
 // first strictly smallest positive one (src/scene.rs:164-166, 325-340): ties go to the
 // lowest object index.  `prev` is the entry just before the winner in that sorted list
@@ -212,8 +232,20 @@ __device__ __forceinline__ V3 phong_lighting(const DevLight& L, const DevObject&
     V3 rd = -(ld - (normal * 2.0) * ldn);
     double rde = dot3(rd, eye);
     if (rde >= 0.0) {
-      double factor = pow(rde, ob.shininess);
-      specular = (intensity * ob.specular) * factor;
+      // The highlight is added last: where it is below a quarter ulp of every channel of
+      // ambient + diffuse the f64 sum does not change, and `pow` (the costliest call of the
+      // shading model) is skipped.  FP32 estimate of log2 of the highlight, with 2 bits of margin.
+      const V3 base = ambient + diffuse;
+      const double base_min = fmin(base.x, fmin(base.y, base.z));
+      const double gain = fmax(fabs(intensity.x), fmax(fabs(intensity.y), fabs(intensity.z))) * fabs(ob.specular);
+      const float sh = (float)ob.shininess;
+      const float lg_factor = sh * __log2f((float)rde) + 2.0f;        // -inf for rde == 0
+      const float lg_room = __log2f((float)base_min / (float)gain) - 55.0f;  // NaN or -inf when there is no room
+      const bool negligible = sh > 0.0f && sh < 1.0e6f && rde <= 1.0 && base_min > 0.0 && lg_factor < lg_room;
+      if (!negligible) {
+        double factor = pow(rde, ob.shininess);
+        specular = (intensity * ob.specular) * factor;
+      }
     }
   }
   return (ambient + diffuse) + specular;

@@ -18,8 +18,8 @@ namespace rtk {
 template <typename ExactFn>
 __device__ __forceinline__ void sweep_primary(const DevScene& S, const float4* __restrict__ prim, float4* s_buf, bool active,
                                               float dx, float dy, float dz, ExactFn&& exact) {
-  for (uint32_t base = 0; base < S.n_spheres_padded; base += kChunk) {
-    const uint32_t count = min((uint32_t)kChunk, S.n_spheres_padded - base);
+  for (uint32_t base = 0; base < S.n_spheres_grouped; base += kChunk) {
+    const uint32_t count = min((uint32_t)kChunk, S.n_spheres_grouped - base);
     stage_chunk(s_buf, prim, base, count);
     if (!__any(active)) continue;  // wavefront has no live ray: only help with staging
     for (uint32_t j = 0; j < count; j += kGroup) {
@@ -67,8 +67,8 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, float4* s_buf, b
                                              const float (&gx)[NR], const float (&gy)[NR], const float (&gz)[NR],
                                              const float (&rho)[NR], float thr, ExactFn&& exact, DoneFn&& done) {
   bool wave_live = __any(active);
-  for (uint32_t base = 0; base < S.n_spheres_padded; base += kChunk) {
-    const uint32_t count = min((uint32_t)kChunk, S.n_spheres_padded - base);
+  for (uint32_t base = 0; base < S.n_spheres_grouped; base += kChunk) {
+    const uint32_t count = min((uint32_t)kChunk, S.n_spheres_grouped - base);
     stage_chunk(s_buf, S.sph_filter, base, count);
     if (!wave_live) continue;
     for (uint32_t j = 0; j < count; j += kGroup) {
@@ -133,14 +133,16 @@ __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, float4* s_buf, 
     if (need) {
       for (uint32_t r = 0; r < nb; ++r) {
         const DevLight& L = S.lights[kb + r];
-        V3 lv = ld3(L.pos) - p;
-        double lw = L.pos[3] - 1.0;
-        double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
-        V3 d = {lv.x / m, lv.y / m, lv.z / m};
-        double dw = lw / m;
         for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
+          const DevObject& ob = S.objects[S.plane_object[ip]];
+          if (!plane_may_block(ob, L, p)) continue;
+          V3 lv = ld3(L.pos) - p;
+          double lw = L.pos[3] - 1.0;
+          double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+          V3 d = {lv.x / m, lv.y / m, lv.z / m};
+          double dw = lw / m;
           double t0, t1;
-          int n = intersect_object(S.objects[S.plane_object[ip]], p, d, dw, t0, t1);
+          int n = intersect_object(ob, p, d, dw, t0, t1);
           if (n >= 1 && t0 > 0.0 && t0 < m) occl |= 1u << r;
         }
       }

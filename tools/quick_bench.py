@@ -4,6 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 rtk = importlib.import_module("raytracer-rust_amd")
 device = importlib.import_module("raytracer-rust_amd.device")
+if os.environ.get("RTK_LIB"):
+    device.LIB_PATH = os.environ["RTK_LIB"]  # experiment builds
 dev = device.Device(0)
 names = sys.argv[1:] or ["C2", "C3", "C4"]
 for name in names:

@@ -44,7 +44,7 @@ def cpu_baseline(rtk, scene, camera):
     threads = max(1, min(16, os.cpu_count() or 1))
     w, h = camera.width, camera.height
     # centre crop; sized for roughly 10-30 s of CPU work on the 10k-sphere frame
-    cw, ch = (512, 288) if len(scene.nodes) > 2000 else (1024, 576)
+    cw, ch = (1024, 576) if len(scene.nodes) > 2000 else (1920, 1080)
     cw, ch = min(cw, w), min(ch, h)
     x0, y0 = (w - cw) // 2, (h - ch) // 2 + h // 8
     y0 = min(y0, h - ch)
@@ -114,7 +114,7 @@ def main():
         if world > 1:
             tdist.barrier()
 
-    kernel_ms = []
+    kernel_ms, rays_ms = [], []
     local_rays = 0
 
     def step(record):
@@ -123,6 +123,7 @@ def main():
         if record:
             st = dev.stats()  # waits for this step's kernel; HIP events around the trace kernel
             kernel_ms.append(st.kernel_ms)
+            rays_ms.append(st.rays_ms)
             local_rays = st.rays
 
     for _ in range(args.warmup):
@@ -146,14 +147,18 @@ def main():
 
     if rank == 0:
         avg_kernel_ms = sum(kernel_ms) / max(1, len(kernel_ms))
-        achieved = local_rays * fpr / (avg_kernel_ms * 1e-3) / 1e12 if avg_kernel_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if world == 1 and os.path.exists(tpath):
+        avg_rays_ms = sum(rays_ms) / max(1, len(rays_ms))
+        # the dominant kernel traces every ray of the launch (camera + shadow): its algorithmic
+        # work is the brute-force sweep the reference performs for those rays
+        achieved = local_rays * fpr / (avg_rays_ms * 1e-3) / 1e12 if avg_rays_ms > 0 else 0.0
+        measured = {}
+        mpath = os.path.join(ROOT, "profiles", "measured_counters.json")
+        if world == 1 and os.path.exists(mpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("bytes_per_launch")
+                measured = json.load(open(mpath)).get(args.workload, {})
             except Exception:
-                traffic = None
+                measured = {}
+        traffic = measured.get("hbm_bytes_per_launch")
         out = {
             "metric": "Mrays/sec at 3840x2160 (1/2/4/8 MI355X) + % of FP32 VALU peak",
             "value": frame_rays * args.steps / elapsed / 1e6,
@@ -177,7 +182,7 @@ def main():
             "pct_fp32_valu_peak": 100.0 * (frame_rays * fpr * args.steps / elapsed / 1e12) / (PEAK_FP32_TFLOPS * world),
             "roofline": {
                 "bound": "valu",
-                "kernel": "render_kernel (rank 0)",
+                "kernel": "trace_uniform_kernel (camera + shadow rays, rank 0)",
                 "achieved": achieved,
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
@@ -185,9 +190,14 @@ def main():
                 "traffic": traffic,
                 "flops_per_ray": fpr,
                 "rays_per_launch": int(local_rays),
-                "kernel_ms": avg_kernel_ms,
-                "note": "achieved = algorithmic flops (26 per ray-sphere test, 8 per ray-plane test) / HIP-event kernel time; "
-                        "the kernel executes fewer instructions than that count, so the fraction can exceed 1",
+                "kernel_ms": avg_rays_ms,
+                "all_kernels_ms": avg_kernel_ms,
+                "measured_valu_issue_util": measured.get("valu_issue_util"),
+                "note": "achieved = algorithmic flops of the reference's sweep (26 per ray-sphere test, 8 per ray-plane "
+                        "test, every ray against every object) / HIP-event time of the ray kernel. The kernel culls "
+                        "whole clusters of spheres per wavefront and executes far fewer instructions than that count, "
+                        "so the fraction exceeds 1; measured_valu_issue_util (rocprofv3 PMC, profiles/) is the share of "
+                        "SIMD issue cycles the kernel really uses",
             },
         }
         if world == 1 and not args.no_extra:

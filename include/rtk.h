@@ -112,7 +112,10 @@ typedef struct rtk_stats {
   uint64_t rays_shadow;
   uint64_t rays_secondary;
   uint64_t exact_tests; /* (ray, object) pairs that needed the f64 re-evaluation */
-  double kernel_ms;     /* HIP-event time of the trace kernel(s) of the last call */
+  double kernel_ms;     /* HIP-event time of the ray and shading kernels of the last call */
+  double rays_ms;       /* ... of the ray kernels alone (camera + shadow + secondary rays); equals kernel_ms
+                           when rays and shading run in one kernel (scenes with reflective or
+                           transparent materials, rtk_trace_rays) */
 } rtk_stats;
 
 /* Which tiles of the frame a call renders.  Tiles are RTK_TILE_W x RTK_TILE_H pixels,

@@ -93,6 +93,7 @@ class rtk_stats(C.Structure):
         ("rays_secondary", C.c_uint64),
         ("exact_tests", C.c_uint64),
         ("kernel_ms", C.c_double),
+        ("rays_ms", C.c_double),
     ]
 
     @property

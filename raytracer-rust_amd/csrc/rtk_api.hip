@@ -160,10 +160,11 @@ struct rtk_scene_handle {
 struct rtk_context {
   int device = -1;
   hipStream_t stream = nullptr;
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  hipEvent_t ev_start = nullptr, ev_rays = nullptr, ev_stop = nullptr;  // ev_rays: end of the ray kernels
   rtk::DevCounters* d_counters = nullptr;
   hipStream_t last_stream = nullptr;
   bool have_timing = false;
+  bool split_timing = false;  // ev_rays was recorded by the last call
   // staging for rtk_render (host-buffer variant)
   float* d_rgb = nullptr;
   uint8_t* d_rgba8 = nullptr;
@@ -255,6 +256,7 @@ int rtk_create(int device_id, rtk_context** out) {
   ctx->device = device_id;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&ctx->ev_start)) != hipSuccess || (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
+      (e = hipEventCreate(&ctx->ev_rays)) != hipSuccess ||
       (e = hipMalloc((void**)&ctx->d_counters, sizeof(rtk::DevCounters) * rtk::kCounterShards)) != hipSuccess ||
       (e = hipMemset(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards)) != hipSuccess) {
     rtk_destroy(ctx);
@@ -274,9 +276,9 @@ void rtk_destroy(rtk_context* ctx) {
   if (ctx->opaque.hit_obj) (void)hipFree(ctx->opaque.hit_obj);
   if (ctx->opaque.hit_t) (void)hipFree(ctx->opaque.hit_t);
   if (ctx->opaque.shadow) (void)hipFree(ctx->opaque.shadow);
-  if (ctx->opaque.over) (void)hipFree(ctx->opaque.over);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  if (ctx->ev_rays) (void)hipEventDestroy(ctx->ev_rays);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -602,8 +604,6 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
 
   RTK_HIP(hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-  RTK_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, st));
-  RTK_HIP(rtk::launch_prep_primary(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball, scene->d_prim_cluster));
   const bool opaque = !scene->dev.any_secondary;
   if (opaque) {
     // intermediate hit / shadow records: one entry per pixel of this launch
@@ -612,19 +612,21 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
       if (ctx->opaque.hit_obj) (void)hipFree(ctx->opaque.hit_obj);
       if (ctx->opaque.hit_t) (void)hipFree(ctx->opaque.hit_t);
       if (ctx->opaque.shadow) (void)hipFree(ctx->opaque.shadow);
-      if (ctx->opaque.over) (void)hipFree(ctx->opaque.over);
       ctx->opaque = rtk::OpaqueBuffers{};
       ctx->cap_opaque = 0;
       RTK_HIP(hipMalloc((void**)&ctx->opaque.hit_obj, need * sizeof(uint32_t)));
       RTK_HIP(hipMalloc((void**)&ctx->opaque.hit_t, need * sizeof(double)));
       RTK_HIP(hipMalloc((void**)&ctx->opaque.shadow, need));
-      RTK_HIP(hipMalloc((void**)&ctx->opaque.over, need * 3 * sizeof(double)));
       ctx->cap_opaque = need;
     }
   }
-  RTK_HIP(hipEventRecord(ctx->ev_start, st));
+  RTK_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, st));
+  RTK_HIP(rtk::launch_prep_primary(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball, scene->d_prim_cluster));
+  RTK_HIP(hipEventRecord(ctx->ev_start, st));  // the per-camera record kernel (microseconds) stays outside
+  ctx->split_timing = opaque;
   if (opaque)
-    RTK_HIP(rtk::launch_render_opaque(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball, scene->d_prim_cluster, t, ctx->opaque, ctx->d_counters));
+    RTK_HIP(rtk::launch_render_opaque(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball, scene->d_prim_cluster, t,
+                                      ctx->opaque, ctx->d_counters, ctx->ev_rays));
   else
     RTK_HIP(rtk::launch_render(st, scene->dev, cam, scene->d_prim, t, ctx->d_counters));
   RTK_HIP(hipEventRecord(ctx->ev_stop, st));
@@ -641,6 +643,8 @@ int rtk_get_stats(rtk_context* ctx, rtk_stats* stats) {
   RTK_HIP(hipEventSynchronize(ctx->ev_stop));
   float ms = 0.f;
   RTK_HIP(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+  float rays_ms = ms;
+  if (ctx->split_timing) RTK_HIP(hipEventElapsedTime(&rays_ms, ctx->ev_start, ctx->ev_rays));
   rtk::DevCounters shards[rtk::kCounterShards];
   RTK_HIP(hipMemcpyAsync(shards, ctx->d_counters, sizeof shards, hipMemcpyDeviceToHost, ctx->last_stream));
   RTK_HIP(hipStreamSynchronize(ctx->last_stream));
@@ -651,6 +655,7 @@ int rtk_get_stats(rtk_context* ctx, rtk_stats* stats) {
     stats->exact_tests += c.exact_tests;
   }
   stats->kernel_ms = ms;
+  stats->rays_ms = rays_ms;
   return RTK_OK;
 }
 
@@ -706,6 +711,7 @@ int rtk_trace_rays(rtk_context* ctx, rtk_scene_handle* scene, const double* orig
   if (e == hipSuccess) e = hipMemcpyAsync(d_o, origins, n * 4 * sizeof(double), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_d, directions, n * 4 * sizeof(double), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, st);
+  ctx->split_timing = false;
   if (e == hipSuccess) e = hipEventRecord(ctx->ev_start, st);
   if (e == hipSuccess) e = rtk::launch_trace_rays(st, scene->dev, d_o, d_d, n, d_c, ctx->d_counters);
   if (e == hipSuccess) e = hipEventRecord(ctx->ev_stop, st);

@@ -96,7 +96,6 @@ struct OpaqueBuffers {
   uint32_t* hit_obj;  // object index of the closest hit, 0xffffffff = miss
   double* hit_t;      // its ray parameter
   uint8_t* shadow;    // bit 7: in shadow; bits 0..6: shadow rays the reference traces for this hit
-  double* over;       // shading point (x | y | z planes of n entries each), read back by the exact shadow tests
 };
 
 struct RenderTarget {

@@ -18,12 +18,12 @@ hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamer
 hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim, const RenderTarget& T,
                          DevCounters* counters);
 
-// Same for scenes without reflective or transparent materials: three lean kernels
-// (camera rays, shadow rays, shading) with intermediate records in B.
+// Same for scenes without reflective or transparent materials: ray kernel(s) (camera +
+// shadow rays) and a shading kernel, with intermediate records in B.  `after_rays`, when not
+// null, is recorded between the two.
 hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
                                 const float4* prim_ball, const float4* prim_cluster, const RenderTarget& T,
-                                const OpaqueBuffers& B,
-                                DevCounters* counters);
+                                const OpaqueBuffers& B, DevCounters* counters, hipEvent_t after_rays);
 
 // Traces n caller-supplied rays (device pointers, n x 4 doubles in, n x 3 doubles out).
 hipError_t launch_trace_rays(hipStream_t st, const DevScene& S, const double* origins, const double* directions, uint64_t n,

@@ -1,39 +1,41 @@
 // rtk_opaque.hip -- the render path for scenes without reflective or transparent
-// materials (every throughput configuration): three lean kernels instead of one.
+// materials (every throughput configuration): lean kernels instead of one.
 //
-//   primary_kernel   two pixels per lane; camera-ray sweep over all spheres (FP32 filter,
-//                    f64 on candidates), planes exact; writes the hit (object, t)
-//   shadow_*_kernel  rebuilds the shading point of each hit, sweeps all spheres for all
-//                    lights at once, writes the reference's shadow flag and ray count
+//   trace_uniform_kernel  (every light has w = 0) one pixel per lane: the camera ray, then
+//                    the shadow rays of its hit towards all lights; writes the hit
+//                    (object, t), the reference's shadow flag and its shadow-ray count
+//   primary_kernel + shadow_general_kernel   the same in two kernels when some light has w != 0
 //   shade_kernel     rebuilds LightingData, samples the texture, sums Phong over the
 //                    lights and stores FP32 RGB + RGBA8 (transposed through LDS)
 //
-// Nothing of the f64 shading state is live across a sweep, so the sweep kernels fit in 64
-// VGPRs and run 8 wavefronts per SIMD.  The intermediate records (13 bytes per pixel) make
-// one round trip through HBM; that is noise next to the sweeps (tens of ms at 4K).
+// Only 13 bytes per pixel of intermediate state cross HBM between the ray kernel and the
+// shading kernel; the f64 shading state is rebuilt where it is needed.
 //
-// Arithmetic of the decisions is unchanged from the single-kernel path (rtk_kernels.hip):
-// conservative FP32 filter, then the reference's own f64 formulas with contraction off.
+// Arithmetic of the decisions is the same as in the single-kernel path (rtk_kernels.hip):
+// conservative FP32 tests decide which (ray, object) pairs are looked at, then the
+// reference's own f64 formulas with contraction off decide the outcome.
 //
-// Wavefront-level early-out.  The 64 rays of a wavefront patch (8x8 pixels) are coherent:
+// Wavefront-level culling.  The 64 rays of a wavefront (an 8x8 pixel patch) are coherent:
 // camera rays fill a narrow cone, shadow rays towards a w = 0 light are parallel lines
-// through a small ball of shading points.  Each sweep over the object list therefore runs
-// in two levels:
-//   level 1  the lanes take 64 DIFFERENT spheres each and test them against the patch's
-//            bundle (cone / fattened line), about 14 VALU instructions per 64 spheres per
-//            bundle; a ballot gives the spheres some ray of the patch might touch;
-//   level 2  only for those, the per-ray FP32 filter (one ray per lane, the sphere
-//            broadcast), then f64 on the candidates it keeps.
-// Both levels are conservative, every (ray, sphere) pair of the object list is covered by
-// one of the tests, and the f64 decisions are the same as before.
+// through a small ball of shading points.  The spheres are ordered at scene upload into
+// spatial clusters of 64 with one bounding ball each (rtk_scene_upload), and a sweep over
+// the object list runs in three levels:
+//   level 0  the lanes take 64 DIFFERENT clusters each and test their balls against the
+//            patch's bundle (cone / fattened lines); a ballot gives the clusters to open;
+//   level 1  for an opened cluster the lanes take its 64 member spheres, same test;
+//   level 2  for the spheres that are left, the per-ray FP32 filter (one ray per lane, the
+//            sphere record wavefront-uniform), then f64 on the candidates it keeps.
+// Every level is conservative (it may keep too much, never too little), every (ray, sphere)
+// pair of the object list is covered by one of the tests, and the f64 decisions are those of
+// a plain sweep.  Records are read straight from global memory (they are wavefront-uniform
+// or one coalesced line per wavefront): no LDS staging, no workgroup barriers.
 //
 // When every light of the scene has w = 0 (lights loaded from scene files,
 // src/loader.rs:35-40) the shadow ray's line direction g_k = L_k/|L_k| is the same for
-// every shading point, so the per-(sphere, light) part of the filter is tabulated at scene
-// upload: K[j][k] = c_j.g_k - R_j'^2 rho_k.  With P_k = p.g_k per lane,
-// h = u.g_k + R^2 rho_k = P_k - K[j][k]: two VALU instructions per (ray, sphere) plus a
-// seventh of the shared |p - c|^2 work.  Two pixels per lane keep the LDS reads (32 bytes
-// per sphere) below the VALU time.
+// every shading point, so the per-(sphere, light) part of the level-2 filter is tabulated at
+// scene upload: K[j][k] = c_j.g_k - R_j'^2 rho_k.  With P_k = p.g_k per lane,
+// h = u.g_k + R^2 rho_k = P_k - K[j][k]: two VALU instructions per (ray, sphere, light) plus
+// the shared |p - c|^2 work.
 
 #include "rtk_shading.h"
 #include "rtk_sweeps.h"
@@ -105,99 +107,75 @@ __device__ __forceinline__ bool cone_reaches(const Cone& c, float4 ball) {
 }
 
 // ------------------------------------------------------------------------------------
-// Kernel 1: camera rays.  Workgroup b owns local tiles 2b' and 2b'+1 (bottom of the frame
-// first); each lane traces the same slot of both tiles, each wavefront two 8x8 patches.
-__global__ void __launch_bounds__(kBlock, 4) primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
-                                                           const float4* __restrict__ prim_ball,
-                                                           const float4* __restrict__ prim_cluster, RenderTarget T,
-                                                           OpaqueBuffers B, DevCounters* counters) {
-  const uint32_t pairs = (T.n_local_tiles + 1u) / 2u;
-  const uint32_t pr = pairs - 1u - blockIdx.x;
-  const PixelRef pa = pixel_ref(T, C, 2u * pr), pb = pixel_ref(T, C, 2u * pr + 1u);
+// Camera-ray phase of one pixel per lane; each wavefront owns one 8x8 patch.  Planes exact,
+// spheres through the three levels (clusters, members, per-ray filter) and f64 on what is left.
+__device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera& C, const float4* __restrict__ prim,
+                                              const float4* __restrict__ prim_ball,
+                                              const float4* __restrict__ prim_cluster, const PixelRef& px, Closest& best,
+                                              unsigned& n_exact) {
   const V3 origin = ld3(C.origin);
   const uint32_t lane = threadIdx.x & 63u;
-
-  Closest best_a, best_b;
-  closest_init(best_a);
-  closest_init(best_b);
-  float ax, ay, az, bx, by, bz;
-  unsigned n_exact = 0;
+  closest_init(best);
+  float dx, dy, dz;
   {
-    const V3 da = camera_ray_direction(C, pa.x, pa.y), db = camera_ray_direction(C, pb.x, pb.y);
-    ax = (float)da.x, ay = (float)da.y, az = (float)da.z;
-    bx = (float)db.x, by = (float)db.y, bz = (float)db.z;
+    const V3 d = camera_ray_direction(C, px.x, px.y);
+    dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
     for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
       const uint32_t obj = S.plane_object[ip];
       double t0, t1;
-      if (pa.valid && intersect_object(S.objects[obj], origin, da, 0.0, t0, t1)) closest_consider(best_a, t0, obj, false);
-      if (pb.valid && intersect_object(S.objects[obj], origin, db, 0.0, t0, t1)) closest_consider(best_b, t0, obj, false);
+      if (px.valid && intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) closest_consider(best, t0, obj, false);
     }
   }
+  if (!wave_any(px.valid)) return;
   // pixels outside the frame still have well-defined directions; they only widen the cone a little
-  const Cone cone_a = make_cone(ax, ay, az), cone_b = make_cone(bx, by, bz);
-  const bool live_a = wave_any(pa.valid), live_b = wave_any(pb.valid);
-
-  if (live_a || live_b) {
-    for (uint32_t cbase = 0; cbase < S.n_clusters_padded; cbase += kBundle) {
-      // level 0: this lane's cluster against both cones
-      const float4 cl = prim_cluster[cbase + lane];
-      const unsigned long long ca = live_a ? __builtin_amdgcn_ballot_w64(cone_reaches(cone_a, cl)) : 0ull;
-      const unsigned long long cb = live_b ? __builtin_amdgcn_ballot_w64(cone_reaches(cone_b, cl)) : 0ull;
-      for (unsigned long long cm = ca | cb; cm != 0ull; cm &= cm - 1ull) {
-        const uint32_t cbit = (uint32_t)__builtin_ctzll(cm);
-        const uint32_t first = (cbase + cbit) * kBundle;
-        // level 1: this lane's sphere of the cluster against the cones that reach the cluster
-        const float4 ball = prim_ball[first + lane];
-        const unsigned long long ma = ((ca >> cbit) & 1ull) ? __builtin_amdgcn_ballot_w64(cone_reaches(cone_a, ball)) : 0ull;
-        const unsigned long long mb = ((cb >> cbit) & 1ull) ? __builtin_amdgcn_ballot_w64(cone_reaches(cone_b, ball)) : 0ull;
-        // level 2: per-ray filter and exact test for the spheres level 1 kept
-        for (unsigned long long m = ma | mb; m != 0ull; m &= m - 1ull) {
-          const uint32_t bit = (uint32_t)__builtin_ctzll(m);
-          const uint32_t j = first + bit;
-          const float4 r = prim[j];
-          float ta = r.x * ax;
-          ta = __builtin_fmaf(r.y, ay, ta);
-          ta = __builtin_fmaf(r.z, az, ta);
-          float tb = r.x * bx;
-          tb = __builtin_fmaf(r.y, by, tb);
-          tb = __builtin_fmaf(r.z, bz, tb);
-          const bool pass_a = pa.valid && ((ma >> bit) & 1ull) && __builtin_fmaf(ta, ta, -r.w) >= 0.0f;
-          const bool pass_b = pb.valid && ((mb >> bit) & 1ull) && __builtin_fmaf(tb, tb, -r.w) >= 0.0f;
-          if (wave_any(pass_a || pass_b)) {
-            const uint32_t obj = S.sph_object[j];
+  const Cone cone = make_cone(dx, dy, dz);
+  for (uint32_t cbase = 0; cbase < S.n_clusters_padded; cbase += kBundle) {
+    // level 0: this lane's cluster against the cone
+    unsigned long long cm = __builtin_amdgcn_ballot_w64(cone_reaches(cone, prim_cluster[cbase + lane]));
+    for (; cm != 0ull; cm &= cm - 1ull) {
+      const uint32_t first = (cbase + (uint32_t)__builtin_ctzll(cm)) * kBundle;
+      // level 1: this lane's sphere of the cluster against the cone
+      unsigned long long m = __builtin_amdgcn_ballot_w64(cone_reaches(cone, prim_ball[first + lane]));
+      // level 2: per-ray filter and exact test for the spheres level 1 kept
+      for (; m != 0ull; m &= m - 1ull) {
+        const uint32_t j = first + (uint32_t)__builtin_ctzll(m);
+        const float4 r = prim[j];
+        float t = r.x * dx;
+        t = __builtin_fmaf(r.y, dy, t);
+        t = __builtin_fmaf(r.z, dz, t);
+        const bool pass = px.valid && __builtin_fmaf(t, t, -r.w) >= 0.0f;
+        if (wave_any(pass)) {
+          const uint32_t obj = S.sph_object[j];
+          if (pass) {
+            ++n_exact;
             double t0, t1;
-            if (pass_a) {
-              ++n_exact;
-              const V3 d = camera_ray_direction(C, launder(pa.x), pa.y);
-              if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
-                closest_consider(best_a, t0, obj, false);
-                closest_consider(best_a, t1, obj, false);
-              }
-            }
-            if (pass_b) {
-              ++n_exact;
-              const V3 d = camera_ray_direction(C, launder(pb.x), pb.y);
-              if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
-                closest_consider(best_b, t0, obj, false);
-                closest_consider(best_b, t1, obj, false);
-              }
+            const V3 d = camera_ray_direction(C, launder(px.x), px.y);
+            if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
+              closest_consider(best, t0, obj, false);
+              closest_consider(best, t1, obj, false);
             }
           }
         }
       }
     }
   }
-  if (pa.in_range) {
-    B.hit_obj[pa.local] = pa.valid ? best_a.obj : 0xffffffffu;
-    B.hit_t[pa.local] = best_a.t;
-  }
-  if (pb.in_range) {
-    B.hit_obj[pb.local] = pb.valid ? best_b.obj : 0xffffffffu;
-    B.hit_t[pb.local] = best_b.t;
-  }
-  unsigned n_primary = wave_sum((pa.valid ? 1u : 0u) + (pb.valid ? 1u : 0u));
+}
+
+// Kernel 1 (scenes with some light of w != 0): camera rays only.  Workgroup b owns local
+// tile n - 1 - b (bottom of the frame first).
+__global__ void __launch_bounds__(kBlock, 4) primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
+                                                           const float4* __restrict__ prim_ball,
+                                                           const float4* __restrict__ prim_cluster, RenderTarget T,
+                                                           OpaqueBuffers B, DevCounters* counters) {
+  const PixelRef px = pixel_ref(T, C, T.n_local_tiles - 1u - blockIdx.x);
+  Closest best;
+  unsigned n_exact = 0;
+  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, n_exact);
+  B.hit_obj[px.local] = px.valid ? best.obj : 0xffffffffu;
+  B.hit_t[px.local] = best.t;
+  const unsigned n_primary = wave_sum(px.valid ? 1u : 0u);
   n_exact = wave_sum(n_exact);
-  if (lane == 0) {
+  if ((threadIdx.x & 63u) == 0) {
     atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)n_primary);
     atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
   }
@@ -292,80 +270,42 @@ __device__ __forceinline__ Ball make_ball(bool live, float x, float y, float z) 
 }
 
 // ------------------------------------------------------------------------------------
-// Kernel 2a: shadow rays when every light has w = 0.  KW = lights per batch (4 or 8).
+// Shadow phase of one pixel per lane when every light has w = 0: `Scene::is_shadowed`
+// (src/scene.rs:208-225) for the shading point p.  KW = lights per batch (4 or 8).
 //
-// Level 1 for one light: the patch's shadow lines are parallel to g and pass through the
+// Level 0/1 for one light: the patch's shadow lines are parallel to g and pass through the
 // ball {m, rho_w}.  A line through p can touch sphere {c, R} only if its distance from c is
 // at most R_e = R sqrt(1 + 2 |rho| (-s) + R^2 rho^2), s = (p - c).g (the reference's growing
 // ball, see PixelFilter).  Over the ball of points: distance(c, line through m) <=
-// rho_w + R + R |rho| max(rho_w - s_m, 0) + R^3 rho^2 / 2.
+// rho_w + R + R |rho| max(rho_w - s_m, 0) + R^3 rho^2 / 2.  For a cluster {C, Rc} around its
+// members' balls the same holds with R -> Rc in the reach, s_m -> s_m - Rc, and the growth
+// terms taken with the scene's largest sphere radius.
 template <int KW>
-__global__ void __launch_bounds__(kBlock, KW == 4 ? 4 : 3) shadow_uniform_kernel(DevScene S, DevCamera C, RenderTarget T,
-                                                                                OpaqueBuffers B, DevCounters* counters) {
+__device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool need, V3 p, unsigned& n_rays, unsigned& n_exact) {
   constexpr int KV = KW / 4;  // float4 per table row
-  const uint32_t pairs = (T.n_local_tiles + 1u) / 2u;
-  const uint32_t pr = pairs - 1u - blockIdx.x;
-  const PixelRef pa = pixel_ref(T, C, 2u * pr), pb = pixel_ref(T, C, 2u * pr + 1u);
   const uint32_t lane = threadIdx.x & 63u;
-
-  uint32_t obj_a = 0xffffffffu, obj_b = 0xffffffffu;
-  if (pa.valid) obj_a = B.hit_obj[pa.local];
-  if (pb.valid) obj_b = B.hit_obj[pb.local];
-  bool need_a = obj_a != 0xffffffffu, need_b = obj_b != 0xffffffffu;
-  // The f64 shading points are needed only by the exact tests; they are parked in HBM and
-  // re-read there so that they do not occupy 12 VGPRs across the sweep.
-  const size_t stride = (size_t)T.n_local_tiles * 256u;
-  if (need_a) {
-    const V3 p = over_point(S, C, pa, obj_a, B.hit_t[pa.local]);
-    B.over[pa.local] = p.x, B.over[stride + pa.local] = p.y, B.over[2 * stride + pa.local] = p.z;
-  }
-  if (need_b) {
-    const V3 p = over_point(S, C, pb, obj_b, B.hit_t[pb.local]);
-    B.over[pb.local] = p.x, B.over[stride + pb.local] = p.y, B.over[2 * stride + pb.local] = p.z;
-  }
-  auto load_p = [&](const PixelRef& px) {
-    const uint32_t i = launder(px.local);
-    return V3{B.over[i], B.over[stride + i], B.over[2 * stride + i]};
-  };
-
-  unsigned rays_a = 0, rays_b = 0, n_exact = 0;
-  bool shadow_a = false, shadow_b = false;
-
-#if RTK_EXP == 1
-  need_a = need_b = false;
-#endif
+  unsigned rays = 0;
+  bool in_shadow = false;
   for (uint32_t kb = 0, batch = 0; kb < S.n_lights; kb += KW, ++batch) {
-    if (!wave_any(need_a || need_b)) break;
+    if (!wave_any(need)) break;
     const uint32_t nb = min((uint32_t)KW, S.n_lights - kb);
-    uint32_t occl_a = 0, occl_b = 0;
-    PixelFilter<KW> fa, fb;
-    park(fa);
-    park(fb);
-    bool live_a = false, live_b = false;
-    if (need_a) {
-      const V3 p = load_p(pa);
+    uint32_t occl = 0;
+    PixelFilter<KW> f;
+    park(f);
+    bool live = false;
+    if (need) {
       for (uint32_t r = 0; r < nb; ++r)
         for (uint32_t ip = 0; ip < S.n_planes; ++ip)
           if (plane_may_block(S.objects[S.plane_object[ip]], S.lights[kb + r], p) &&
               shadow_ray_blocked(S.objects[S.plane_object[ip]], S.lights[kb + r], p))
-            occl_a |= 1u << r;
-      live_a = !(occl_a & 1u);
-      if (live_a) arm(fa, S, p, kb, nb);
-    }
-    if (need_b) {
-      const V3 p = load_p(pb);
-      for (uint32_t r = 0; r < nb; ++r)
-        for (uint32_t ip = 0; ip < S.n_planes; ++ip)
-          if (plane_may_block(S.objects[S.plane_object[ip]], S.lights[kb + r], p) &&
-              shadow_ray_blocked(S.objects[S.plane_object[ip]], S.lights[kb + r], p))
-            occl_b |= 1u << r;
-      live_b = !(occl_b & 1u);
-      if (live_b) arm(fb, S, p, kb, nb);
+            occl |= 1u << r;
+      live = !(occl & 1u);
+      if (live) arm(f, S, p, kb, nb);
     }
     const float4* __restrict__ ktab = S.k_table + (size_t)batch * S.n_spheres_padded * KV;
 
-    // bundles of the two patches; the slack covers the FP32 rounding of points and centres
-    const Ball ball_a = make_ball(live_a, fa.x, fa.y, fa.z), ball_b = make_ball(live_b, fb.x, fb.y, fb.z);
+    // bundle of the patch; the slack covers the FP32 rounding of points and centres
+    const Ball ball = make_ball(live, f.x, f.y, f.z);
     float lgx[KW], lgy[KW], lgz[KW], lrho[KW];
     float grow = 0.0f;
 #pragma unroll
@@ -374,17 +314,15 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 4 : 3) shadow_uniform_kernel
       lgx[k] = lf.x, lgy[k] = lf.y, lgz[k] = lf.z, lrho[k] = fabsf(lf.w) * 1.0001f;
       grow = fmaxf(grow, 0.5f * S.r_max * S.r2_max * lf.w * lf.w);
     }
-    const float pad_a = ball_a.radius + grow * 1.01f +
-                        16.0f * kEps32 * (fabsf(ball_a.mx) + fabsf(ball_a.my) + fabsf(ball_a.mz) + ball_a.radius + S.c_max);
-    const float pad_b = ball_b.radius + grow * 1.01f +
-                        16.0f * kEps32 * (fabsf(ball_b.mx) + fabsf(ball_b.my) + fabsf(ball_b.mz) + ball_b.radius + S.c_max);
+    const float pad = ball.radius + grow * 1.01f +
+                      16.0f * kEps32 * (fabsf(ball.mx) + fabsf(ball.my) + fabsf(ball.mz) + ball.radius + S.c_max);
 
     // rec = {centre, radius} of a sphere (t_extra = 0, growth radius = its own) or of a
     // cluster (t_extra = its radius, growth radius = the scene's largest sphere radius)
-    auto lines_reach = [&](const Ball& bl, float pad, float4 rec, float t_extra, float r_grow) {
-      const float ux = bl.mx - rec.x, uy = bl.my - rec.y, uz = bl.mz - rec.z;
+    auto lines_reach = [&](float4 rec, float t_extra, float r_grow) {
+      const float ux = ball.mx - rec.x, uy = ball.my - rec.y, uz = ball.mz - rec.z;
       const float reach = rec.w + pad;  // R + rho_w + slack
-      const float tb = bl.radius + t_extra;
+      const float tb = ball.radius + t_extra;
       bool pass = false;
 #pragma unroll
       for (int k = 0; k < KW; ++k) {
@@ -398,68 +336,41 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 4 : 3) shadow_uniform_kernel
       return pass;
     };
 
-    bool wave_live = wave_any(live_a || live_b);
-#if RTK_EXP == 2
-    wave_live = false;
-#endif
+    bool wave_live = wave_any(live);
     for (uint32_t cbase = 0; wave_live && cbase < S.n_clusters_padded; cbase += kBundle) {
-      // level 0: this lane's cluster against the line bundles of both patches
+      // level 0: this lane's cluster against the patch's line bundles
       const float4 cl = S.cluster_ball[cbase + lane];
-      const unsigned long long ca =
-          wave_any(live_a) ? __builtin_amdgcn_ballot_w64(lines_reach(ball_a, pad_a, cl, cl.w, S.r_max)) : 0ull;
-      const unsigned long long cb =
-          wave_any(live_b) ? __builtin_amdgcn_ballot_w64(lines_reach(ball_b, pad_b, cl, cl.w, S.r_max)) : 0ull;
-      for (unsigned long long cm = ca | cb; wave_live && cm != 0ull; cm &= cm - 1ull) {
-        const uint32_t cbit = (uint32_t)__builtin_ctzll(cm);
-        const uint32_t first = (cbase + cbit) * kBundle;
+      unsigned long long cm = __builtin_amdgcn_ballot_w64(lines_reach(cl, cl.w, S.r_max));
+      for (; wave_live && cm != 0ull; cm &= cm - 1ull) {
+        const uint32_t first = (cbase + (uint32_t)__builtin_ctzll(cm)) * kBundle;
         // level 1: this lane's sphere of the cluster
         const float4 rec = S.sph_ball[first + lane];
-        const unsigned long long ma =
-            ((ca >> cbit) & 1ull) && wave_any(live_a) ? __builtin_amdgcn_ballot_w64(lines_reach(ball_a, pad_a, rec, 0.0f, rec.w)) : 0ull;
-        const unsigned long long mb =
-            ((cb >> cbit) & 1ull) && wave_any(live_b) ? __builtin_amdgcn_ballot_w64(lines_reach(ball_b, pad_b, rec, 0.0f, rec.w)) : 0ull;
+        unsigned long long m = __builtin_amdgcn_ballot_w64(lines_reach(rec, 0.0f, rec.w));
         bool changed = false;
         // level 2: per-ray tabulated filter, then the exact test
-        for (unsigned long long m = ma | mb; m != 0ull; m &= m - 1ull) {
-          const uint32_t bit = (uint32_t)__builtin_ctzll(m);
-          const uint32_t j = first + bit;
+        for (; m != 0ull; m &= m - 1ull) {
+          const uint32_t j = first + (uint32_t)__builtin_ctzll(m);
           const float4 c = S.sph_tab[j];
-          const float pca = __builtin_fmaf(fa.z, c.z, __builtin_fmaf(fa.y, c.y, fa.x * c.x));
-          const float pcb = __builtin_fmaf(fb.z, c.z, __builtin_fmaf(fb.y, c.y, fb.x * c.x));
-          const float ea = __builtin_fmaf(pca, kTwoKappa, -c.w), eb = __builtin_fmaf(pcb, kTwoKappa, -c.w);
-          uint32_t mask_a = 0, mask_b = 0;
+          const float pc = __builtin_fmaf(f.z, c.z, __builtin_fmaf(f.y, c.y, f.x * c.x));
+          const float e = __builtin_fmaf(pc, kTwoKappa, -c.w);
+          uint32_t mask = 0;
 #pragma unroll
           for (int v = 0; v < KV; ++v) {
             const float4 row = ktab[(size_t)j * KV + v];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int k = v * 4 + e;
-              const float kv = (&row.x)[e];
-              const float ha = fa.P[k] - kv, hb = fb.P[k] - kv;
-              if (__builtin_fmaf(ha, ha, ea) >= fa.thrp) mask_a |= 1u << k;
-              if (__builtin_fmaf(hb, hb, eb) >= fb.thrp) mask_b |= 1u << k;
+            for (int i = 0; i < 4; ++i) {
+              const float h = f.P[v * 4 + i] - (&row.x)[i];
+              if (__builtin_fmaf(h, h, e) >= f.thrp) mask |= 1u << (v * 4 + i);
             }
           }
-          if (!((ma >> bit) & 1ull)) mask_a = 0;
-          if (!((mb >> bit) & 1ull)) mask_b = 0;
-          mask_a &= ~occl_a;
-          mask_b &= ~occl_b;
-          if (wave_any((mask_a | mask_b) != 0)) {
+          mask &= ~occl;
+          if (wave_any(mask != 0)) {
             const DevObject& ob = S.objects[S.sph_object[j]];
-            if (mask_a) {
-              const V3 p = load_p(pa);
+            if (mask) {
               for (uint32_t r = 0; r < nb; ++r)
-                if ((mask_a >> r) & 1u) {
+                if ((mask >> r) & 1u) {
                   ++n_exact;
-                  if (shadow_ray_blocked(ob, S.lights[kb + r], p)) occl_a |= 1u << r;
-                }
-            }
-            if (mask_b) {
-              const V3 p = load_p(pb);
-              for (uint32_t r = 0; r < nb; ++r)
-                if ((mask_b >> r) & 1u) {
-                  ++n_exact;
-                  if (shadow_ray_blocked(ob, S.lights[kb + r], p)) occl_b |= 1u << r;
+                  if (shadow_ray_blocked(ob, S.lights[kb + r], p)) occl |= 1u << r;
                 }
             }
             changed = true;
@@ -467,44 +378,54 @@ __global__ void __launch_bounds__(kBlock, KW == 4 ? 4 : 3) shadow_uniform_kernel
         }
         if (changed) {
           // a pixel whose first light is blocked needs nothing more: park it
-          if (live_a && (occl_a & 1u)) {
-            live_a = false;
-            park(fa);
+          if (live && (occl & 1u)) {
+            live = false;
+            park(f);
           }
-          if (live_b && (occl_b & 1u)) {
-            live_b = false;
-            park(fb);
-          }
-          wave_live = wave_any(live_a || live_b);
+          wave_live = wave_any(live);
         }
       }
     }
-    const uint32_t lights_mask = (nb >= 32u) ? 0xffffffffu : ((1u << nb) - 1u);
-    if (need_a) {
-      occl_a &= lights_mask;
-      if (occl_a) {
-        rays_a += (unsigned)__builtin_ctz(occl_a) + 1u;
-        shadow_a = true;
-        need_a = false;
+    if (need) {
+      occl &= (nb >= 32u) ? 0xffffffffu : ((1u << nb) - 1u);
+      if (occl) {
+        rays += (unsigned)__builtin_ctz(occl) + 1u;
+        in_shadow = true;
+        need = false;
       } else {
-        rays_a += nb;
-      }
-    }
-    if (need_b) {
-      occl_b &= lights_mask;
-      if (occl_b) {
-        rays_b += (unsigned)__builtin_ctz(occl_b) + 1u;
-        shadow_b = true;
-        need_b = false;
-      } else {
-        rays_b += nb;
+        rays += nb;
       }
     }
   }
-  if (pa.in_range) B.shadow[pa.local] = (uint8_t)((shadow_a ? 0x80u : 0u) | rays_a);
-  if (pb.in_range) B.shadow[pb.local] = (uint8_t)((shadow_b ? 0x80u : 0u) | rays_b);
+  n_rays += rays;
+  return in_shadow;
+}
+
+// Kernels 1+2 fused (every light has w = 0): camera ray, then the shadow rays of its hit.
+template <int KW>
+__global__ void __launch_bounds__(kBlock, 4) trace_uniform_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
+                                                                 const float4* __restrict__ prim_ball,
+                                                                 const float4* __restrict__ prim_cluster, RenderTarget T,
+                                                                 OpaqueBuffers B, DevCounters* counters) {
+  const PixelRef px = pixel_ref(T, C, T.n_local_tiles - 1u - blockIdx.x);
+  Closest best;
+  unsigned n_exact = 0;
+  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, n_exact);
+  const uint32_t obj = px.valid ? best.obj : 0xffffffffu;
+  const bool hit = obj != 0xffffffffu;
+  B.hit_obj[px.local] = obj;
+  B.hit_t[px.local] = best.t;
+  V3 p = {0, 0, 0};
+  if (hit) p = over_point(S, C, px, obj, best.t);
+  unsigned rays = 0;
+  const bool in_shadow = shadow_phase_uniform<KW>(S, hit, p, rays, n_exact);
+  B.shadow[px.local] = (uint8_t)((in_shadow ? 0x80u : 0u) | rays);
+  const unsigned n_primary = wave_sum(px.valid ? 1u : 0u);
   n_exact = wave_sum(n_exact);
-  if (lane == 0) atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
+  if ((threadIdx.x & 63u) == 0) {
+    atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)n_primary);
+    atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
+  }
 }
 
 // Kernel 2b: shadow rays for arbitrary lights (some w != 0): one pixel per lane, per-lane
@@ -596,17 +517,17 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, 
 // ------------------------------------------------------------------------------------
 hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
                                 const float4* prim_ball, const float4* prim_cluster, const RenderTarget& T,
-                                const OpaqueBuffers& B, DevCounters* counters) {
-  if (T.n_local_tiles == 0) return hipSuccess;
-  const dim3 pairs((T.n_local_tiles + 1u) / 2u), tiles(T.n_local_tiles), block(kBlock);
+                                const OpaqueBuffers& B, DevCounters* counters, hipEvent_t after_rays) {
+  if (T.n_local_tiles == 0) return after_rays ? hipEventRecord(after_rays, st) : hipSuccess;
+  const dim3 tiles(T.n_local_tiles), block(kBlock);
   if (S.max_depth > 0) {
-    hipLaunchKernelGGL(primary_kernel, pairs, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);
     if (S.lights_uniform) {
       if (S.k_width == 4)
-        hipLaunchKernelGGL((shadow_uniform_kernel<4>), pairs, block, 0, st, S, C, T, B, counters);
+        hipLaunchKernelGGL((trace_uniform_kernel<4>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);
       else
-        hipLaunchKernelGGL((shadow_uniform_kernel<8>), pairs, block, 0, st, S, C, T, B, counters);
+        hipLaunchKernelGGL((trace_uniform_kernel<8>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);
     } else {
+      hipLaunchKernelGGL(primary_kernel, tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);
       switch (light_batch_for(S.n_lights)) {
         case 1: hipLaunchKernelGGL((shadow_general_kernel<1>), tiles, block, 0, st, S, C, T, B, counters); break;
         case 2: hipLaunchKernelGGL((shadow_general_kernel<2>), tiles, block, 0, st, S, C, T, B, counters); break;
@@ -617,6 +538,10 @@ hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCame
   } else {
     // MAX_DEPTH 0: trace_inner returns the ambient colour without intersecting anything
     hipError_t e = hipMemsetAsync(B.hit_obj, 0xff, (size_t)T.n_local_tiles * 256u * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+  }
+  if (after_rays) {
+    hipError_t e = hipEventRecord(after_rays, st);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(shade_kernel, tiles, block, 0, st, S, C, T, B, counters);

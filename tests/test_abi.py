@@ -34,7 +34,7 @@ def test_struct_sizes_match_the_header_layout(rtk):
     assert C.sizeof(a.rtk_light) == 7 * 8
     assert C.sizeof(a.rtk_scene) == 8 + 8 + 8 + 8 + 24 + 8
     assert C.sizeof(a.rtk_camera) == 8 + 4 * 8 + 16 * 8
-    assert C.sizeof(a.rtk_stats) == 5 * 8
+    assert C.sizeof(a.rtk_stats) == 6 * 8
     assert C.sizeof(a.rtk_tiling) == 8
 
 

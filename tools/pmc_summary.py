@@ -44,3 +44,26 @@ for name, counters in sorted(agg.items()):
         print(f"   {k:24s} {v:.6g}" if isinstance(v, float) else f"   {k:24s} {v}")
 if "--json" in sys.argv:
     json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+if "--measured" in sys.argv:
+    # profiles/measured_counters.json: what bench.py quotes for the dominant kernel of a workload.
+    # HBM bytes per launch = WRITE_SIZE + 2 x FETCH_SIZE (both KiB; on gfx950 FETCH_SIZE tallies the
+    # 128-byte requests of wide coalesced loads at 64 bytes).
+    path, workload = sys.argv[sys.argv.index("--measured") + 1], sys.argv[sys.argv.index("--measured") + 2]
+    name = max((k for k in out if out[k].get("avg_ms")), key=lambda k: out[k]["avg_ms"])
+    d = out[name]
+    try:
+        allw = json.load(open(path))
+    except Exception:
+        allw = {}
+    allw[workload] = {
+        "kernel": name,
+        "avg_ms_rocprof": d["avg_ms"],
+        "hbm_bytes_per_launch": int((d.get("WRITE_SIZE", 0.0) + 2.0 * d.get("FETCH_SIZE", 0.0)) * 1024),
+        "write_bytes": int(d.get("WRITE_SIZE", 0.0) * 1024),
+        "fetch_bytes_corrected": int(2.0 * d.get("FETCH_SIZE", 0.0) * 1024),
+        "valu_issue_util": d.get("valu_issue_util"),
+        "avg_waves_per_simd": d.get("avg_waves_per_simd"),
+        "clock_GHz": d.get("clock_GHz"),
+        "source": src,
+    }
+    json.dump(allw, open(path, "w"), indent=1)

@@ -250,3 +250,108 @@ def test_empty_scene_and_no_spheres(rtk, dev, oracle):
     scene.add_light(rtk.PointLight(rtk.vec3(0, 5, 0)))
     scene.add_object(rtk.Plane())
     check_against_oracle(dev, oracle, scene, camera, "plane only")
+
+
+# ---------------------------------------------------------------- cluster / bundle culling under stress
+def _random_field(rtk, rng, n, affine, r_lo, r_hi, extent, lights, planes=1):
+    """n opaque spheres scattered in a box (overlaps allowed), optionally general affine."""
+    M = rtk.Matrix4x4
+    scene = rtk.Scene()
+    for pos in lights:
+        scene.add_light(rtk.PointLight(pos, rtk.rgb(*(1.0 / len(lights),) * 3)))
+    mat = rtk.Material.default()
+    if planes >= 1:
+        scene.add_object(rtk.Plane().with_material(mat.with_pattern(rtk.Texture.checker(rtk.WHITE, rtk.BLACK)).with_specular(0.0)))
+    if planes >= 2:
+        scene.add_object(rtk.Plane().with_material(mat.with_color(rtk.rgb(0.4, 0.5, 0.6)))
+                         .with_transform(M.translate(0, 0, extent * 1.2) * M.rotate_x(math.pi / 2 - 0.2)))
+    for _ in range(n):
+        r = float(np.exp(rng.uniform(np.log(r_lo), np.log(r_hi))))
+        c = (rng.uniform(-extent, extent), rng.uniform(0.0, 0.4 * extent), rng.uniform(0.0, 2 * extent))
+        t = M.translate(*c)
+        if affine:
+            t = t * M.rotate_y(rng.uniform(0, 6.28)) * M.rotate_x(rng.uniform(0, 6.28)) * \
+                M.scale(r * rng.uniform(0.3, 1.0), r * rng.uniform(0.3, 1.0), r)
+        else:
+            t = t * M.scale(r, r, r)
+        col = rtk.rgb(*rng.uniform(0.2, 1.0, size=3))
+        scene.add_object(rtk.Sphere().with_material(mat.with_color(col)).with_transform(t))
+    return scene
+
+
+def _field_camera(rtk, extent, w, h, eye=None, to=None):
+    camera = rtk.Camera(w, h, rtk.PI / 3)
+    camera.transform = rtk.Matrix4x4.look_at(eye or rtk.point(0, 0.5 * extent, -0.6 * extent),
+                                             to or rtk.point(0, 0, 0.9 * extent), rtk.vec3(0, 1, 0))
+    return camera
+
+
+@pytest.mark.parametrize("seed,affine", [(1, False), (2, True), (3, True)])
+def test_clustered_fields_w0_lights(rtk, dev, oracle, seed, affine):
+    """Several hundred overlapping spheres of very different sizes (many clusters, large r_max
+    against small spheres), general affine in two of the cases, two planes, w = 0 lights."""
+    rng = np.random.default_rng(seed)
+    E = 20.0
+    lights = [rtk.vec3(-0.8 * E, 1.5 * E, -0.5 * E), rtk.vec3(0.9 * E, 1.1 * E, 0.3 * E), rtk.vec3(0.1 * E, 2.0 * E, 2.5 * E)]
+    scene = _random_field(rtk, rng, 700, affine, 0.05, 4.0, E, lights, planes=2)
+    check_against_oracle(dev, oracle, scene, _field_camera(rtk, E, 192, 108), f"field seed {seed}")
+
+
+def test_lights_near_the_origin_and_inside_the_field(rtk, dev, oracle):
+    """w = 0 lights close to the world origin make rho = -1/|L| large: the reference's shadow
+    rays then bend strongly (the target ball grows quickly along the ray)."""
+    rng = np.random.default_rng(11)
+    E = 12.0
+    lights = [rtk.vec3(0.3, 0.8, 0.2), rtk.vec3(-2.0, 3.0, 6.0), rtk.vec3(0.0, 0.05, 0.0), rtk.vec3(4.0, 1.0, 14.0)]
+    scene = _random_field(rtk, rng, 400, False, 0.1, 1.5, E, lights)
+    check_against_oracle(dev, oracle, scene, _field_camera(rtk, E, 160, 90), "near lights")
+
+
+def test_clustered_field_w1_and_mixed_lights(rtk, dev, oracle):
+    """Lights built from points (w = 1) and a mix of w = 0 / w = 1 take the two-kernel path."""
+    rng = np.random.default_rng(5)
+    E = 15.0
+    scene = _random_field(rtk, rng, 300, True, 0.1, 2.0, E, [rtk.point(-10, 20, -8), rtk.point(12, 9, 20)])
+    check_against_oracle(dev, oracle, scene, _field_camera(rtk, E, 160, 90), "w=1 lights")
+    scene.lights[0] = rtk.PointLight(rtk.vec3(-10, 20, -8), rtk.rgb(0.5, 0.5, 0.5))
+    check_against_oracle(dev, oracle, scene, _field_camera(rtk, E, 160, 90), "mixed lights")
+
+
+def test_camera_inside_the_field_looking_everywhere(rtk, dev, oracle):
+    """The camera sits between the spheres (some patches' cones contain whole clusters, others
+    look away from all of them) and inside one of them."""
+    rng = np.random.default_rng(8)
+    E = 10.0
+    scene = _random_field(rtk, rng, 500, False, 0.2, 1.2, E, [rtk.vec3(-6, 18, -4), rtk.vec3(7, 15, 25)])
+    for eye, to in ((rtk.point(0.3, 2.0, 9.0), rtk.point(4, 1, 15)), (rtk.point(0.3, 2.0, 9.0), rtk.point(-3, 6, -2)),
+                    (rtk.point(1, 30, 10), rtk.point(1, 0, 10.001))):
+        check_against_oracle(dev, oracle, scene, _field_camera(rtk, E, 128, 72, eye, to), "inside field")
+    big = rtk.Sphere().with_material(rtk.Material.default().with_color(rtk.rgb(0.7, 0.2, 0.2))) \
+        .with_transform(rtk.Matrix4x4.translate(0.3, 2.0, 9.0) * rtk.Matrix4x4.scale(3, 3, 3))
+    scene.add_object(big)
+    check_against_oracle(dev, oracle, scene, _field_camera(rtk, E, 128, 72, rtk.point(0.3, 2.0, 9.0), rtk.point(4, 1, 15)), "inside a sphere")
+
+
+def test_sphere_counts_around_the_cluster_size(rtk, dev, oracle):
+    """63, 64, 65, 128, 129 spheres: partial last cluster, padding records."""
+    for n in (1, 7, 63, 64, 65, 128, 129):
+        scene = rtk.synthetic.make_scene(n, True, 3, 77 + n)
+        camera = rtk.synthetic.make_camera(n, 160, 90)
+        check_against_oracle(dev, oracle, scene, camera, f"{n} spheres")
+
+
+def test_large_coordinates(rtk, dev, oracle):
+    """The field far from the world origin (FP32 records are recentred on the field, the
+    lights' quirk term scales with the distance from the origin)."""
+    rng = np.random.default_rng(21)
+    E = 10.0
+    scene = _random_field(rtk, rng, 200, False, 0.2, 1.5, E, [rtk.vec3(-6, 18, -4), rtk.vec3(7, 15, 25)], planes=0)
+    M = rtk.Matrix4x4
+    shift = M.translate(3000.0, -200.0, 1500.0)
+    for node in scene.nodes:
+        node.transform = shift * node.transform
+    scene.lights = [rtk.PointLight(rtk.vec3(2990.0, -170.0, 1490.0), rtk.rgb(0.6, 0.6, 0.6)),
+                    rtk.PointLight(rtk.vec3(3010.0, -180.0, 1530.0), rtk.rgb(0.4, 0.4, 0.4))]
+    camera = rtk.Camera(160, 90, rtk.PI / 3)
+    camera.transform = M.look_at(rtk.point(3000.0, -195.0, 1494.0), rtk.point(3000.0, -200.0, 1509.0), rtk.vec3(0, 1, 0))
+    check_against_oracle(dev, oracle, scene, camera, "large coordinates")

@@ -46,10 +46,7 @@ def _build_material(packed):
     if packed is None:
         return host.Material.default()
     d = host.Material.default()
-    known = {"texture", "ambient", "diffuse", "specular", "shininess", "transparency", "reflectivity", "refractivity"}
-    for key in packed:
-        if key not in known:
-            raise ValueError(f"material: unknown field {key!r}")
+    # fields the reference's structs do not name are ignored, as serde does (src/loader.rs:99-109)
     get = lambda k, dv: float(packed[k]) if packed.get(k) is not None else dv
     return host.Material(
         texture=_build_texture(packed.get("texture")),

@@ -170,14 +170,14 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {n_sph} spheres + {n_pl} plane(s), {len(scene.lights)} lights, "
                             f"{camera.width}x{camera.height}, 1 spp, opaque materials",
                 "rays_per_frame": int(frame_rays),
                 "tiles": "32x8 px tiles dealt round-robin to ranks; FP32 RGB + RGBA8 gathered to rank 0",
-                "precision": "FP32 candidate filter over all objects; f64 exact intersection and shading; FP32/RGBA8 store",
+                "precision": "every decision and colour in f64 (the reference's formulas); FP32 only in the conservative culling tests; FP32 RGB + RGBA8 store",
             },
             "pct_fp32_valu_peak": 100.0 * (frame_rays * fpr * args.steps / elapsed / 1e12) / (PEAK_FP32_TFLOPS * world),
             "roofline": {

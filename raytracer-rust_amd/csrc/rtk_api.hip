@@ -628,7 +628,7 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
     RTK_HIP(rtk::launch_render_opaque(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball, scene->d_prim_cluster, t,
                                       ctx->opaque, ctx->d_counters, ctx->ev_rays));
   else
-    RTK_HIP(rtk::launch_render(st, scene->dev, cam, scene->d_prim, t, ctx->d_counters));
+    RTK_HIP(rtk::launch_render(st, scene->dev, cam, scene->d_prim, scene->d_prim_cluster, t, ctx->d_counters));
   RTK_HIP(hipEventRecord(ctx->ev_stop, st));
   ctx->last_stream = st;
   ctx->have_timing = true;

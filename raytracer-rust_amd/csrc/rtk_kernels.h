@@ -15,8 +15,8 @@ hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamer
                                float4* prim_cluster);
 
 // Renders the tiles selected by T.
-hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim, const RenderTarget& T,
-                         DevCounters* counters);
+hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
+                         const float4* prim_cluster, const RenderTarget& T, DevCounters* counters);
 
 // Same for scenes without reflective or transparent materials: ray kernel(s) (camera +
 // shadow rays) and a shading kernel, with intermediate records in B.  `after_rays`, when not

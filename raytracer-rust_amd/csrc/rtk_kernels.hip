@@ -41,7 +41,8 @@ struct StackEntry {
 };
 
 template <bool SECONDARY, bool PRIMARY_FILTER, int LB>
-__device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restrict__ prim, float4* s_buf, bool valid, V3 o,
+__device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restrict__ prim,
+                                        const float4* __restrict__ prim_cluster, bool valid, V3 o,
                                         V3 d, unsigned& c_primary, unsigned& c_shadow, unsigned& c_secondary,
                                         unsigned& c_exact) {
   V3 color = {0, 0, 0};
@@ -69,7 +70,7 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
           depth = e.depth;
         }
       }
-      if (!__syncthreads_or(have)) break;
+      if (!__any(have)) break;  // the wavefront has run out of rays
     } else if (iter > 0) {
       break;
     }
@@ -82,9 +83,9 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
     }
     Closest best;
     if (PRIMARY_FILTER && (!SECONDARY || iter == 0))
-      closest_primary(S, prim, s_buf, have, ro, rd, best, c_exact);
+      closest_primary(S, prim, prim_cluster, have, ro, rd, best, c_exact);
     else
-      closest_general(S, s_buf, have, ro, rd, best, c_exact);
+      closest_general(S, have, ro, rd, best, c_exact);
 
     const bool hit = have && best.obj != 0xffffffffu;
     if (have && !hit) color = color + scene_ambient * weight;  // trace_inner: miss -> ambient_color
@@ -150,7 +151,7 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
       }
     }
 
-    const bool in_shadow = shadow_sweeps<LB>(S, s_buf, hit, over, c_shadow, c_exact);
+    const bool in_shadow = shadow_sweeps<LB>(S, hit, over, c_shadow, c_exact);
 
     if (hit) {
       const DevObject& ob = S.objects[obj];
@@ -169,8 +170,9 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
 // (src/graphics.rs:44-46, 59-74).
 template <bool SECONDARY, int LB>
 __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
-                                                        RenderTarget T, DevCounters* counters) {
-  __shared__ float4 s_buf[kChunk];
+                                                        const float4* __restrict__ prim_cluster, RenderTarget T,
+                                                        DevCounters* counters) {
+  __shared__ float4 s_buf[256];  // store transpose only: [256][3] floats + [256] packed pixels
 
   // expensive tiles (ground, bottom of the frame) first, cheap sky tiles last
   const uint32_t k = T.n_local_tiles - 1u - blockIdx.x;
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera
   const V3 dir = camera_ray_direction(C, x, y);  // cameras.rs:52-69
 
   unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
-  V3 color = trace_ray<SECONDARY, true, LB>(S, prim, s_buf, valid, origin, dir, c_primary, c_shadow, c_secondary, c_exact);
+  V3 color = trace_ray<SECONDARY, true, LB>(S, prim, prim_cluster, valid, origin, dir, c_primary, c_shadow, c_secondary, c_exact);
 
   // ---- framebuffer store, transposed through LDS so that every wavefront writes whole
   // 128-byte (RGBA8) / 384-byte (FP32 RGB) tile rows
@@ -241,7 +243,6 @@ template <int LB>
 __global__ void __launch_bounds__(kBlock) trace_rays_kernel(DevScene S, const double* __restrict__ origins,
                                                             const double* __restrict__ directions, uint64_t n,
                                                             double* __restrict__ colors, DevCounters* counters) {
-  __shared__ float4 s_buf[kChunk];
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool valid = i < n;
   V3 o = {0, 0, 0}, d = {0, 0, 1};
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(kBlock) trace_rays_kernel(DevScene S, const do
     d = ld3(directions + 4 * i);
   }
   unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
-  V3 color = trace_ray<true, false, LB>(S, nullptr, s_buf, valid, o, d, c_primary, c_shadow, c_secondary, c_exact);
+  V3 color = trace_ray<true, false, LB>(S, nullptr, nullptr, valid, o, d, c_primary, c_shadow, c_secondary, c_exact);
   if (valid) {
     colors[3 * i + 0] = color.x;
     colors[3 * i + 1] = color.y;
@@ -336,12 +337,13 @@ __global__ void __launch_bounds__(kBlock) untile_kernel(uint32_t width, uint32_t
 
 template <bool SECONDARY>
 static hipError_t launch_render_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, const DevCamera& C,
-                                   const float4* prim, const RenderTarget& T, DevCounters* counters) {
+                                   const float4* prim, const float4* prim_cluster, const RenderTarget& T,
+                                   DevCounters* counters) {
   switch (lb) {
-    case 1: hipLaunchKernelGGL((render_kernel<SECONDARY, 1>), grid, dim3(kBlock), 0, st, S, C, prim, T, counters); break;
-    case 2: hipLaunchKernelGGL((render_kernel<SECONDARY, 2>), grid, dim3(kBlock), 0, st, S, C, prim, T, counters); break;
-    case 4: hipLaunchKernelGGL((render_kernel<SECONDARY, 4>), grid, dim3(kBlock), 0, st, S, C, prim, T, counters); break;
-    default: hipLaunchKernelGGL((render_kernel<SECONDARY, 8>), grid, dim3(kBlock), 0, st, S, C, prim, T, counters); break;
+    case 1: hipLaunchKernelGGL((render_kernel<SECONDARY, 1>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
+    case 2: hipLaunchKernelGGL((render_kernel<SECONDARY, 2>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
+    case 4: hipLaunchKernelGGL((render_kernel<SECONDARY, 4>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
+    default: hipLaunchKernelGGL((render_kernel<SECONDARY, 8>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
   }
   return hipGetLastError();
 }
@@ -362,13 +364,13 @@ hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamer
   return hipGetLastError();
 }
 
-hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim, const RenderTarget& T,
-                         DevCounters* counters) {
+hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
+                         const float4* prim_cluster, const RenderTarget& T, DevCounters* counters) {
   if (T.n_local_tiles == 0) return hipSuccess;
   dim3 grid(T.n_local_tiles);
   const int lb = light_batch_for(S.n_lights);
-  if (S.any_secondary) return launch_render_lb<true>(lb, grid, st, S, C, prim, T, counters);
-  return launch_render_lb<false>(lb, grid, st, S, C, prim, T, counters);
+  if (S.any_secondary) return launch_render_lb<true>(lb, grid, st, S, C, prim, prim_cluster, T, counters);
+  return launch_render_lb<false>(lb, grid, st, S, C, prim, prim_cluster, T, counters);
 }
 
 hipError_t launch_trace_rays(hipStream_t st, const DevScene& S, const double* origins, const double* directions, uint64_t n,

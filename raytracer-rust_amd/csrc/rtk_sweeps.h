@@ -1,6 +1,14 @@
-// rtk_sweeps.h -- the brute-force object sweeps with one ray (or one shading point) per
-// lane: camera rays, general rays, and the fused shadow rays with per-lane light
-// directions.  Device code only (included by .hip files after rtk_shading.h).
+// rtk_sweeps.h -- object sweeps with one ray (or one shading point) per lane, for rays that
+// are not bundled per wavefront: secondary rays, shadow rays with per-lane light directions,
+// caller-supplied rays, and the camera rays of the single-kernel path.  Device code only
+// (included by .hip files after rtk_shading.h).
+//
+// The spheres are stored in spatial clusters of kBundle with one bounding ball each
+// (rtk_scene_upload).  A sweep walks the clusters; each lane tests ITS ray against the
+// cluster's ball, and the wavefront opens a cluster only when some lane's ray can reach it.
+// Inside an opened cluster the per-ray filter runs over groups of kGroup sphere records,
+// then f64 on the candidates.  Records are wavefront-uniform loads from global memory: no
+// LDS staging and no workgroup barriers.
 #ifndef RTK_SWEEPS_H
 #define RTK_SWEEPS_H
 
@@ -11,21 +19,29 @@
 namespace rtk {
 
 // ------------------------------------------------------------------------------------
-// Primary rays: all rays of a frame leave from the camera origin, so the per-sphere part
+// Camera rays: all rays of a frame leave from the camera origin, so the per-sphere part
 // of the test is hoisted into the record {L = c - o, CC = |L|^2 (1 - slack) - R'^2}.
 // With a unit direction d the line can touch the bounding ball only if (L.d)^2 >= CC:
 // 3 multiply-adds, one fused square-and-subtract and a share of a max per test.
+// Cluster record {L, Rs} (Rs carries its own rounding slack): the line misses the cluster
+// when its distance from L exceeds Rs.
 template <typename ExactFn>
-__device__ __forceinline__ void sweep_primary(const DevScene& S, const float4* __restrict__ prim, float4* s_buf, bool active,
-                                              float dx, float dy, float dz, ExactFn&& exact) {
-  for (uint32_t base = 0; base < S.n_spheres_grouped; base += kChunk) {
-    const uint32_t count = min((uint32_t)kChunk, S.n_spheres_grouped - base);
-    stage_chunk(s_buf, prim, base, count);
-    if (!__any(active)) continue;  // wavefront has no live ray: only help with staging
-    for (uint32_t j = 0; j < count; j += kGroup) {
+__device__ __forceinline__ void sweep_primary(const DevScene& S, const float4* __restrict__ prim,
+                                              const float4* __restrict__ prim_cluster, bool active, float dx, float dy, float dz,
+                                              ExactFn&& exact) {
+  if (!__any(active)) return;
+  for (uint32_t first = 0; first < S.n_spheres_grouped; first += kBundle) {
+    const float4 cl = prim_cluster[first / kBundle];
+    const float s = __builtin_fmaf(cl.z, dz, __builtin_fmaf(cl.y, dy, cl.x * dx));
+    const float qx = __builtin_fmaf(-s, dx, cl.x), qy = __builtin_fmaf(-s, dy, cl.y), qz = __builtin_fmaf(-s, dz, cl.z);
+    const float d2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+    const bool reach = active && cl.w * cl.w * (1.0f + 8.0f * kEps32) >= d2;
+    if (!__any(reach)) continue;
+    const uint32_t end = min(first + (uint32_t)kBundle, S.n_spheres_grouped);
+    for (uint32_t j = first; j < end; j += kGroup) {
       float4 q[kGroup];
 #pragma unroll
-      for (int g = 0; g < kGroup; ++g) q[g] = s_buf[j + g];
+      for (int g = 0; g < kGroup; ++g) q[g] = prim[j + g];
       float m = -1.0f;
 #pragma unroll
       for (int g = 0; g < kGroup; ++g) {
@@ -34,17 +50,17 @@ __device__ __forceinline__ void sweep_primary(const DevScene& S, const float4* _
         t = __builtin_fmaf(q[g].z, dz, t);
         m = fmaxf(m, __builtin_fmaf(t, t, -q[g].w));
       }
-      if (__any(active && m >= 0.0f)) {
+      if (__any(reach && m >= 0.0f)) {
         // leave the fast loop: find which of the eight records kept a candidate
 #pragma unroll 1
         for (int g = 0; g < kGroup; ++g) {
-          float4 r = s_buf[j + g];
+          float4 r = prim[j + g];
           float t = r.x * dx;
           t = __builtin_fmaf(r.y, dy, t);
           t = __builtin_fmaf(r.z, dz, t);
-          bool pass = active && (__builtin_fmaf(t, t, -r.w) >= 0.0f);
+          bool pass = reach && (__builtin_fmaf(t, t, -r.w) >= 0.0f);
           if (__any(pass)) {
-            uint32_t obj = S.sph_object[base + j + g];
+            uint32_t obj = S.sph_object[j + g];
             if (pass) exact(obj);
           }
         }
@@ -61,20 +77,51 @@ __device__ __forceinline__ void sweep_primary(const DevScene& S, const float4* _
 // The FP32 evaluation keeps a candidate when the computed value is >= thr (<= 0), where
 // kappa (relative, folded into the multiply-add) and thr (absolute, per lane) cover the
 // rounding of inputs and arithmetic.
-
+//
+// Cluster test.  The inequality says the line passes within
+// R_e = R sqrt(1 + 2 |rho| max(-s, 0) + R^2 rho^2) of c, s = u.g (rho <= 0 for lights with
+// w in [0, 1]).  For a cluster ball {C, Rc} around its members' balls, with s_C = (p - C).g:
+//     dist(C, line) <= Rc + r_max |rho| max(Rc - s_C, 0) + r_max^3 rho^2 / 2
+// is necessary for any member to be touched (r_max = largest sphere radius of the scene).
 template <int NR, typename ExactFn, typename DoneFn>
-__device__ __forceinline__ void sweep_filter(const DevScene& S, float4* s_buf, bool& active, float px, float py, float pz,
+__device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, float px, float py, float pz,
                                              const float (&gx)[NR], const float (&gy)[NR], const float (&gz)[NR],
                                              const float (&rho)[NR], float thr, ExactFn&& exact, DoneFn&& done) {
   bool wave_live = __any(active);
-  for (uint32_t base = 0; base < S.n_spheres_grouped; base += kChunk) {
-    const uint32_t count = min((uint32_t)kChunk, S.n_spheres_grouped - base);
-    stage_chunk(s_buf, S.sph_filter, base, count);
-    if (!wave_live) continue;
-    for (uint32_t j = 0; j < count; j += kGroup) {
+  const bool cull = thr > -1.0e38f;  // rays of lights with w outside [0, 1] look at every sphere
+  float lrho[NR];
+  float grow = 0.0f;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    lrho[r] = fabsf(rho[r]) * 1.0001f;
+    grow = fmaxf(grow, 0.5f * S.r_max * S.r2_max * rho[r] * rho[r]);
+  }
+  // covers the FP32 rounding of the point, the centres, the directions and the arithmetic below
+  const float pad = grow * 1.01f + 16.0f * kEps32 * (fabsf(px) + fabsf(py) + fabsf(pz) + S.c_max);
+  for (uint32_t first = 0; wave_live && first < S.n_spheres_grouped; first += kBundle) {
+    bool reach = active;
+    if (cull) {
+      const float4 cl = S.cluster_ball[first / kBundle];
+      const float ux = px - cl.x, uy = py - cl.y, uz = pz - cl.z;
+      const float room = cl.w + pad;
+      bool pass = false;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const float s = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], ux * gx[r]));
+        const float qx = __builtin_fmaf(-s, gx[r], ux), qy = __builtin_fmaf(-s, gy[r], uy), qz = __builtin_fmaf(-s, gz[r], uz);
+        const float d2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+        const float t = fmaxf(cl.w - s, 0.0f) * (1.0f + 8.0f * kEps32);
+        const float rr = __builtin_fmaf(t, S.r_max * lrho[r], room) * (1.0f + 4.0f * kEps32);
+        pass |= rr >= 0.0f && __builtin_fmaf(rr, rr, -d2) >= 0.0f;
+      }
+      reach = active && pass;
+    }
+    if (!__any(reach)) continue;
+    const uint32_t end = min(first + (uint32_t)kBundle, S.n_spheres_grouped);
+    for (uint32_t j = first; j < end; j += kGroup) {
       float4 q[kGroup];
 #pragma unroll
-      for (int g = 0; g < kGroup; ++g) q[g] = s_buf[j + g];
+      for (int g = 0; g < kGroup; ++g) q[g] = S.sph_filter[j + g];
       float m = -3.0e38f;
 #pragma unroll
       for (int g = 0; g < kGroup; ++g) {
@@ -87,10 +134,10 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, float4* s_buf, b
           m = fmaxf(m, __builtin_fmaf(h, h, -cf));
         }
       }
-      if (__any(active && m >= thr)) {
+      if (__any(reach && m >= thr)) {
 #pragma unroll 1
         for (int g = 0; g < kGroup; ++g) {
-          float4 c = s_buf[j + g];
+          float4 c = S.sph_filter[j + g];
           float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
           float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
           float cf = __builtin_fmaf(uu, kKappa, -c.w);
@@ -100,14 +147,14 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, float4* s_buf, b
             float h = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], __builtin_fmaf(ux, gx[r], c.w * rho[r])));
             if (__builtin_fmaf(h, h, -cf) >= thr) mask |= 1u << r;
           }
-          if (!active) mask = 0;
+          if (!reach) mask = 0;
           if (__any(mask != 0)) {
-            uint32_t obj = S.sph_object[base + j + g];
+            uint32_t obj = S.sph_object[j + g];
             if (mask) exact(obj, mask);
           }
         }
         // lanes that need no further test drop out; the wavefront stops once all have
-        if (active && done()) active = false;
+        if (active && done()) active = false, reach = false;
         wave_live = __any(active);
         if (!wave_live) break;
       }
@@ -120,13 +167,13 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, float4* s_buf, b
 // Lights are swept in batches of LB fused rays; the reference stops at the first blocked
 // light, so `n_rays` = index of the first blocked light + 1 (or the light count).
 template <int LB>
-__device__ __forceinline__ bool shadow_sweeps(const DevScene& S, float4* s_buf, bool active, V3 p, unsigned& n_rays,
+__device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3 p, unsigned& n_rays,
                                               unsigned& n_exact) {
   bool in_shadow = false;
   unsigned rays = 0;
   bool need = active;
   for (uint32_t kb = 0; kb < S.n_lights; kb += LB) {
-    if (!__syncthreads_or(need)) break;  // nobody in the tile still needs a light
+    if (!__any(need)) break;  // nobody in the wavefront still needs a light
     const uint32_t nb = min((uint32_t)LB, S.n_lights - kb);
     uint32_t occl = 0;
     // planes: exact, per light (the shadow ray is rebuilt once per light)
@@ -179,7 +226,7 @@ __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, float4* s_buf, 
       }
     };
     auto done = [&]() { return (occl & 1u) != 0; };
-    sweep_filter<LB>(S, s_buf, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done);
+    sweep_filter<LB>(S, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done);
     if (need) {
       occl &= (1u << nb) - 1u;
       if (occl) {
@@ -198,7 +245,7 @@ __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, float4* s_buf, 
 // ------------------------------------------------------------------------------------
 // Closest hit of a general ray (origin o, direction d with w = 0, not necessarily unit):
 // `Scene::intersect` + `HitList::closest_hit` (src/scene.rs:156-169, 325-340).
-__device__ __forceinline__ void closest_general(const DevScene& S, float4* s_buf, bool active, V3 o, V3 d, Closest& best,
+__device__ __forceinline__ void closest_general(const DevScene& S, bool active, V3 o, V3 d, Closest& best,
                                                 unsigned& n_exact) {
   closest_init(best);
   const bool track = S.track_n1 != 0;
@@ -223,12 +270,13 @@ __device__ __forceinline__ void closest_general(const DevScene& S, float4* s_buf
   };
   auto done = [&]() { return false; };
   bool live = active;
-  sweep_filter<1>(S, s_buf, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done);
+  sweep_filter<1>(S, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done);
 }
 
 // Closest hit of a camera ray (unit direction, shared origin).
-__device__ __forceinline__ void closest_primary(const DevScene& S, const float4* __restrict__ prim, float4* s_buf, bool active,
-                                                V3 o, V3 d, Closest& best, unsigned& n_exact) {
+__device__ __forceinline__ void closest_primary(const DevScene& S, const float4* __restrict__ prim,
+                                                const float4* __restrict__ prim_cluster, bool active, V3 o, V3 d,
+                                                Closest& best, unsigned& n_exact) {
   closest_init(best);
   const bool track = S.track_n1 != 0;
   if (active) {
@@ -246,7 +294,7 @@ __device__ __forceinline__ void closest_primary(const DevScene& S, const float4*
       closest_consider(best, t1, obj, track);
     }
   };
-  sweep_primary(S, prim, s_buf, active, (float)d.x, (float)d.y, (float)d.z, exact);
+  sweep_primary(S, prim, prim_cluster, active, (float)d.x, (float)d.y, (float)d.z, exact);
 }
 
 }  // namespace rtk

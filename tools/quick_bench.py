@@ -4,14 +4,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 rtk = importlib.import_module("raytracer-rust_amd")
 device = importlib.import_module("raytracer-rust_amd.device")
-if os.environ.get("RTK_LIB"):
-    device.LIB_PATH = os.environ["RTK_LIB"]  # experiment builds
 dev = device.Device(0)
 names = sys.argv[1:] or ["C2", "C3", "C4"]
 for name in names:
     if name == "C1":
         scene = rtk.PackedScene.from_yaml_file(os.path.join(ROOT, "tests/golden/test01.yaml")).build()
         camera = rtk.Camera(1920, 1080, rtk.PI / 3)
+    elif name in ("C3g", "C4g"):  # the glass variant of a big configuration at 1080p: secondary rays
+        n = 1000 if name == "C3g" else 10000
+        scene = rtk.synthetic.make_scene(n, True, 4, 0xC0FFEE00 + n, glass=True)
+        camera = rtk.synthetic.make_camera(n, 1920, 1080)
+    elif name == "C3w1":           # C3 with w = 1 lights: the two-kernel opaque path
+        scene, camera = rtk.synthetic.config("C3")
+        scene.lights = [rtk.PointLight(rtk.point(*l.position[:3]), l.intensity) for l in scene.lights]
     elif name == "C5s":
         scene, camera = rtk.synthetic.config("C5", 4096, 4096)
     else:

@@ -233,3 +233,42 @@ def lines_reach(fs, ball, lights_xyz, rec, cluster):
         rr = (fma(t, (r_grow * lrho[k]).astype(F), reach) * F(1.0 + 4.0 * float(EPS32))).astype(F)
         ok |= (rr >= 0) & (fma(rr, rr, -d2) >= 0)
     return ok
+
+
+# ---- per-ray cluster tests of the one-ray-per-lane sweeps (csrc/rtk_sweeps.h) ------------------
+
+def ray_reaches_cluster(fs, p, G, omega, clusters):
+    """Cluster test of sweep_filter: ray i (origin p[i], line direction G[i], growth omega[i]/|G[i]|)
+    against every cluster record [m, 4]; -> [rays, clusters]."""
+    p = np.asarray(p, np.float64)
+    G = np.asarray(G, np.float64)
+    omega = np.broadcast_to(np.asarray(omega, np.float64), p.shape[:1])
+    inv = 1.0 / np.sqrt((G * G).sum(axis=1))
+    g = (G * inv[:, None]).astype(F)
+    rho = (omega * inv).astype(F)
+    lrho = (np.abs(rho) * F(1.0001)).astype(F)
+    grow = (F(0.5) * fs.r_max * fs.r2_max * rho * rho).astype(F)
+    pc = (p - fs.center).astype(F)
+    pad = (grow * F(1.01) + F(16.0) * EPS32 * (np.abs(pc[:, 0]) + np.abs(pc[:, 1]) + np.abs(pc[:, 2]) + fs.c_max)).astype(F)
+    cl = clusters[None, :, :]
+    ux, uy, uz = (pc[:, None, 0] - cl[..., 0]).astype(F), (pc[:, None, 1] - cl[..., 1]).astype(F), (pc[:, None, 2] - cl[..., 2]).astype(F)
+    room = (cl[..., 3] + pad[:, None]).astype(F)
+    gx, gy, gz = g[:, None, 0], g[:, None, 1], g[:, None, 2]
+    s = fma(uz, gz, fma(uy, gy, (ux * gx).astype(F)))
+    qx, qy, qz = fma(-s, gx, ux), fma(-s, gy, uy), fma(-s, gz, uz)
+    d2 = fma(qz, qz, fma(qy, qy, (qx * qx).astype(F)))
+    t = (np.maximum((cl[..., 3] - s).astype(F), F(0)) * F(1.0 + 8.0 * float(EPS32))).astype(F)
+    rr = (fma(t, (fs.r_max * lrho)[:, None].astype(F), room) * F(1.0 + 4.0 * float(EPS32))).astype(F)
+    return (rr >= 0) & (fma(rr, rr, -d2) >= 0)
+
+
+def camera_ray_reaches_cluster(directions, records):
+    """Cluster test of sweep_primary: unit FP32 directions [n, 3] against camera-side cluster
+    records {L, Rs} [m, 4]; -> [n, m]."""
+    d = np.asarray(directions, np.float64).astype(F)
+    L = records[None, :, :]
+    dx, dy, dz = d[:, None, 0], d[:, None, 1], d[:, None, 2]
+    s = fma(L[..., 2], dz, fma(L[..., 1], dy, (L[..., 0] * dx).astype(F)))
+    qx, qy, qz = fma(-s, dx, L[..., 0]), fma(-s, dy, L[..., 1]), fma(-s, dz, L[..., 2])
+    d2 = fma(qz, qz, fma(qy, qy, (qx * qx).astype(F)))
+    return (L[..., 3] * L[..., 3] * F(1.0 + 8.0 * float(EPS32))).astype(F) >= d2

@@ -267,3 +267,70 @@ def test_bundle_tests_stay_selective_on_a_c4_like_scene(rtk):
         assert not (hit & ~keep).any()
         kept.append(int(keep.sum()))
     assert max(kept) <= 64, kept
+
+
+# ---- per-ray cluster tests (one ray per lane: secondary rays, shadow rays of any light) ------
+from filter_model import camera_ray_reaches_cluster, ray_reaches_cluster
+
+
+def _random_clusters_around(rng, c, R, per_cluster=8):
+    """Clusters that each contain one of the given spheres plus a few random neighbours."""
+    n = len(c)
+    others_c = c[:, None, :] + rng.normal(size=(n, per_cluster - 1, 3)) * rng.uniform(0.1, 5.0, size=(n, 1, 1))
+    others_R = rng.uniform(0.05, 2.0, size=(n, per_cluster - 1))
+    return np.concatenate([c[:, None, :], others_c], axis=1), np.concatenate([R[:, None], others_R], axis=1)
+
+
+@pytest.mark.parametrize("light_w", [0.0, 1.0, 0.5])
+@pytest.mark.parametrize("scale", [2.0, 50.0, 400.0])
+def test_per_ray_cluster_test_keeps_every_grazing_hit(scale, light_w):
+    rng = np.random.default_rng(int(scale * 7 + light_w * 5))
+    n = 1500
+    p = rng.normal(size=(n, 3)) * scale * 0.4
+    L = np.array([0.3, 1.0, -0.2]) * scale + rng.normal(size=3)
+    s = rng.uniform(-0.5, 1.5, size=(n, 1))
+    c = p + (L - p) * s + rng.normal(size=(n, 3)) * rng.uniform(0.01, 3.0, size=(n, 1))
+    lv = L - p
+    lw = light_w - 1.0
+    m = np.sqrt((lv * lv).sum(axis=1) + lw * lw)
+    d, dw = lv / m[:, None], lw / m
+    Rstar = grazing_radius(p, d, dw, c)
+    G = L - light_w * p
+    for delta in (1e-13, 1e-8, 1e-3):
+        R = Rstar * (1.0 + delta)
+        hit = exact_disc(p, d, dw, c, R) >= 0
+        cc, RR = _random_clusters_around(rng, c, R)
+        fs = FilterScene(cc.reshape(-1, 3), RR.reshape(-1))
+        balls = sphere_balls(fs)
+        clusters = cluster_balls(balls[:, :3], balls[:, 3], bundle=cc.shape[1])  # cluster i holds sphere i first
+        reach = ray_reaches_cluster(fs, p, G, np.full(n, lw), clusters)
+        own = reach[np.arange(n), np.arange(n)]
+        assert not (hit & ~own).any(), f"dropped {int((hit & ~own).sum())} at delta={delta}"
+    # and the test is not vacuous: a plain ray (w = 1) skips most foreign clusters.  (With w < 1 the
+    # adversarial radii here, up to half the distance to the light, make the growing balls reach far.)
+    assert light_w < 1.0 or scale < 50 or reach.mean() < 0.5
+
+
+@pytest.mark.parametrize("scale", [3.0, 60.0, 1500.0])
+def test_camera_ray_cluster_test_keeps_every_grazing_hit(scale):
+    rng = np.random.default_rng(int(scale) + 31)
+    n = 1500
+    origin = rng.normal(size=3) * scale * 0.3
+    d = _unit(rng.normal(size=(n, 3)))
+    dist = scale * rng.uniform(0.02, 1.0, size=(n, 1))
+    perp = _unit(np.cross(d, rng.normal(size=(n, 3))))
+    c = origin + d * dist + perp * rng.uniform(0.01, 2.0, size=(n, 1))
+    p = np.broadcast_to(origin, (n, 3))
+    Rstar = grazing_radius(p, d, np.zeros(n), c)
+    for delta in (1e-13, 1e-8, 1e-3):
+        R = Rstar * (1.0 + delta)
+        hit = exact_disc(p, d, np.zeros(n), c, R) >= 0
+        cc, RR = _random_clusters_around(rng, c, R)
+        fs = FilterScene(cc.reshape(-1, 3), RR.reshape(-1))
+        balls = sphere_balls(fs)
+        cl = cluster_balls(balls[:, :3], balls[:, 3], bundle=cc.shape[1])
+        rec = camera_records(cl[:, :3].astype(np.float64) + fs.center - origin, cl[:, 3].astype(np.float64))
+        reach = camera_ray_reaches_cluster(d, rec)
+        own = reach[np.arange(n), np.arange(n)]
+        assert not (hit & ~own).any(), f"dropped {int((hit & ~own).sum())} at delta={delta}"
+    assert scale < 50 or reach.mean() < 0.5

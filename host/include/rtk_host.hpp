@@ -64,11 +64,27 @@ struct Matrix4x4 {
 struct Texture {
   uint32_t kind = RTK_TEX_SOLID;
   Color a = WHITE, b = BLACK;
-  static Texture solid(Color c) { return {RTK_TEX_SOLID, c, BLACK}; }
-  static Texture checker(Color a, Color b) { return {RTK_TEX_CHECKER, a, b}; }
-  static Texture gradient(Color a, Color b) { return {RTK_TEX_GRADIENT, a, b}; }
-  static Texture ring(Color a, Color b) { return {RTK_TEX_RING, a, b}; }
-  static Texture striped(Color a, Color b) { return {RTK_TEX_STRIPED, a, b}; }
+  bool transformed = false;  // wrapped in a `TransformPattern` (src/graphics/patterns.rs:7-35)
+  Matrix4x4 transform = Matrix4x4::identity();
+  static Texture solid(Color c) { return make(RTK_TEX_SOLID, c, BLACK); }
+  static Texture checker(Color a, Color b) { return make(RTK_TEX_CHECKER, a, b); }
+  static Texture gradient(Color a, Color b) { return make(RTK_TEX_GRADIENT, a, b); }
+  static Texture ring(Color a, Color b) { return make(RTK_TEX_RING, a, b); }
+  static Texture striped(Color a, Color b) { return make(RTK_TEX_STRIPED, a, b); }
+  // `TransformPattern::with_transform`: repeated calls multiply on the right (patterns.rs:22-24)
+  Texture with_transform(const Matrix4x4& t) const {
+    Texture r = *this;
+    r.transformed = true;
+    r.transform = transform * t;
+    return r;
+  }
+
+ private:
+  static Texture make(uint32_t kind, Color a, Color b) {
+    Texture t;
+    t.kind = kind, t.a = a, t.b = b;
+    return t;
+  }
 };
 
 // Defaults of src/scene/materials.rs:34-48.

@@ -77,6 +77,8 @@ void Scene::pack(Packed& st) const {
     const Color a = n.material.texture.a, b = n.material.texture.b;
     m.color_a[0] = a.r, m.color_a[1] = a.g, m.color_a[2] = a.b;
     m.color_b[0] = b.r, m.color_b[1] = b.g, m.color_b[2] = b.b;
+    m.pattern_transformed = n.material.texture.transformed ? 1u : 0u;
+    std::memcpy(m.pattern_transform, n.material.texture.transform.e.data(), sizeof m.pattern_transform);
     m.ambient = n.material.ambient, m.diffuse = n.material.diffuse, m.specular = n.material.specular;
     m.shininess = n.material.shininess, m.transparency = n.material.transparency;
     m.reflectivity = n.material.reflectivity, m.refractivity = n.material.refractivity;

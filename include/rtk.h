@@ -55,14 +55,19 @@ enum { RTK_TEX_SOLID = 0, RTK_TEX_CHECKER = 1, RTK_TEX_GRADIENT = 2, RTK_TEX_RIN
 #define RTK_TILE_W 32
 #define RTK_TILE_H 8
 
-/* `Material` (src/scene/materials.rs:23-32).  For RTK_TEX_SOLID only color_a is used. */
+/* `Material` (src/scene/materials.rs:23-32).  For RTK_TEX_SOLID only color_a is used.
+ * pattern_transformed != 0 wraps the pattern in a `TransformPattern`
+ * (src/graphics/patterns.rs:7-35): the object-space point is multiplied by the inverse of
+ * pattern_transform (row-major) before the pattern is sampled; a singular matrix leaves the
+ * point as it is.  One level of wrapping; scene files cannot express it. */
 typedef struct rtk_material {
   uint32_t texture_kind;
-  uint32_t reserved_;
+  uint32_t pattern_transformed;
   double color_a[3];
   double color_b[3];
   double ambient, diffuse, specular, shininess;
   double transparency, reflectivity, refractivity;
+  double pattern_transform[16];
 } rtk_material;
 
 /* `SceneNode<S>` (src/scene.rs:36-41).  The inverse transform is derived inside the

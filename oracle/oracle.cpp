@@ -242,6 +242,10 @@ inline Ray mul(const Mat4& m, const Ray& r) { return {mul(m, r.origin), mul(m, r
 // ------------------------------------------------------------------ patterns (src/graphics/patterns.rs)
 // Rust's `%` on f64 is C's fmod (sign of the dividend).
 inline Col sample_at(const rtk_material& m, Vec p) {  // src/scene/materials.rs:14-19
+  if (m.pattern_transformed) {  // `TransformPattern::sample_at` (src/graphics/patterns.rs:27-35): inverted per sample
+    Mat4 inverse;
+    if (invert(load16(m.pattern_transform), inverse)) p = mul(inverse, p);
+  }
   Col a = load3(m.color_a), b = load3(m.color_b);
   switch (m.texture_kind) {
     case RTK_TEX_SOLID:

@@ -35,7 +35,7 @@ Double16 = C.c_double * 16
 class rtk_material(C.Structure):
     _fields_ = [
         ("texture_kind", C.c_uint32),
-        ("reserved_", C.c_uint32),
+        ("pattern_transformed", C.c_uint32),
         ("color_a", Double3),
         ("color_b", Double3),
         ("ambient", C.c_double),
@@ -45,6 +45,7 @@ class rtk_material(C.Structure):
         ("transparency", C.c_double),
         ("reflectivity", C.c_double),
         ("refractivity", C.c_double),
+        ("pattern_transform", Double16),
     ]
 
 

@@ -147,6 +147,7 @@ struct rtk_scene_handle {
   void* d_exact = nullptr;
   void* d_sph_object = nullptr;
   void* d_plane_object = nullptr;
+  void* d_pattern_inv = nullptr;
   float4* d_prim = nullptr;  // primary-ray filter records (rebuilt per camera)
   float4* d_prim_ball = nullptr;  // camera-ray records of the wavefront-level cone test (rebuilt per camera)
   void* d_sph_ball = nullptr;
@@ -287,7 +288,7 @@ void rtk_scene_release(rtk_context* ctx, rtk_scene_handle* h) {
   if (!h) return;
   if (ctx) (void)hipSetDevice(ctx->device);
   void* ptrs[] = {h->d_objects, h->d_lights, h->d_filter, h->d_exact, h->d_sph_object, h->d_plane_object, h->d_prim,
-                  h->d_light_filter, h->d_k_table, h->d_sph_tab, h->d_prim_ball, h->d_sph_ball, h->d_cluster_ball, h->d_prim_cluster};
+                  h->d_light_filter, h->d_k_table, h->d_sph_tab, h->d_prim_ball, h->d_sph_ball, h->d_cluster_ball, h->d_prim_cluster, h->d_pattern_inv};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -344,6 +345,7 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   std::vector<DevLight> lights(scene->n_lights);
   std::vector<uint32_t> sph_object, plane_object;
   std::vector<double4> sph_exact;
+  std::vector<double> pattern_inv;  // stays empty unless some pattern has a transform of its own
   bool track_n1 = false, any_secondary = false;
 
   for (uint32_t i = 0; i < scene->n_objects; ++i) {
@@ -374,6 +376,16 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
     std::memcpy(o.plane_normal, src.plane_normal, sizeof o.plane_normal);
     o.kind = src.kind;
     o.texture_kind = src.material.texture_kind;
+    if (src.material.pattern_transformed) {
+      // `TransformPattern` (src/graphics/patterns.rs:27-35): the reference inverts per sample and
+      // samples the untransformed point when the matrix is singular
+      M4 pinv;
+      if (m4_invert(m4_load(src.material.pattern_transform), pinv)) {
+        if (pattern_inv.empty()) pattern_inv.assign(12 * (size_t)scene->n_objects, 0.0);
+        std::memcpy(&pattern_inv[12 * (size_t)i], pinv.e, 12 * sizeof(double));
+        o.texture_kind |= 0x80000000u;
+      }
+    }
     if (o.refractivity != 1.0) track_n1 = true;
     if (!(std::fabs(o.reflectivity) < 0.00001) || !(std::fabs(o.transparency) < 0.00001)) any_secondary = true;
     if (src.kind == RTK_PLANE) {
@@ -518,6 +530,7 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   upload(&h->d_exact, sph_exact.data(), sph_exact.size() * sizeof(double4));
   upload(&h->d_sph_object, sph_object.data(), sph_object.size() * sizeof(uint32_t));
   upload(&h->d_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
+  upload(&h->d_pattern_inv, pattern_inv.data(), pattern_inv.size() * sizeof(double));
   upload(&h->d_light_filter, light_filter.data(), light_filter.size() * sizeof(float4));
   upload(&h->d_k_table, k_table.data(), k_table.size() * sizeof(float));
   upload(&h->d_sph_tab, sph_tab.data(), sph_tab.size() * sizeof(float4));
@@ -537,6 +550,7 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   d.sph_exact = (const double4*)h->d_exact;
   d.sph_object = (const uint32_t*)h->d_sph_object;
   d.plane_object = (const uint32_t*)h->d_plane_object;
+  d.pattern_inv = (const double*)h->d_pattern_inv;
   d.light_filter = (const float4*)h->d_light_filter;
   d.k_table = (const float4*)h->d_k_table;
   d.sph_tab = (const float4*)h->d_sph_tab;

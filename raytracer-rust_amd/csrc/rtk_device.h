@@ -29,7 +29,7 @@ struct DevObject {
   double transparency, reflectivity, refractivity;
   double plane_normal[3];
   uint32_t kind;
-  uint32_t texture_kind;
+  uint32_t texture_kind;  // bit 31: the pattern has a transform of its own, see DevScene::pattern_inv
 };
 
 struct DevLight {
@@ -53,6 +53,7 @@ struct DevScene {
   const double4* sph_exact;     // centre (world, f64) and bounding radius per filter record
   const uint32_t* sph_object;   // filter record -> object index
   const uint32_t* plane_object; // plane list -> object index
+  const double* pattern_inv;    // per object, rows 0..2 of the inverse pattern transform (12 f64); null when no pattern has one
   const float4* light_filter;   // per light: unit line direction g = G/|G| and rho = (w-1)/|G| for G = L.xyz (w = 0 lights)
   const float4* k_table;        // [batch][sphere][k_width]: c_j.g_k - R_j'^2 rho_k, only when lights_uniform
   const float4* sph_tab;        // {cx, cy, cz, kappa |c|^2 - R'^2}: sphere record of the tabulated shadow filter

@@ -99,7 +99,7 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
       over = g.over;
       normal = g.normal;
       eye = g.eye;
-      tex = sample_texture(ob, g.objp);
+      tex = sample_texture_at(S, ob, obj, g.objp);
       if (SECONDARY) {
         // children first, so that nothing of them stays live across the shadow sweep
         const double reflectivity = ob.reflectivity, transparency = ob.transparency;

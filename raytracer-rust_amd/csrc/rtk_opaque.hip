@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, 
       const DevObject& ob = S.objects[obj];
       const V3 d = camera_ray_direction(C, px.x, px.y);
       const HitGeom g = lighting_data(ob, ld3(C.origin), d, B.hit_t[px.local]);
-      const V3 tex = sample_texture(ob, g.objp);
+      const V3 tex = sample_texture_at(S, ob, obj, g.objp);
       V3 surface = ambient;
       for (uint32_t l = 0; l < S.n_lights; ++l)
         surface = surface + phong_lighting(S.lights[l], ob, tex, g.over, g.eye, g.normal, in_shadow);

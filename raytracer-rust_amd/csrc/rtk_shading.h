@@ -163,7 +163,7 @@ __device__ __forceinline__ float filter_threshold(const DevScene& S, V3 pc, floa
 // (src/graphics/patterns.rs:57-65, 81-88, 105-116, 132-140).  Rust's `%` is fmod.
 __device__ __forceinline__ V3 sample_texture(const DevObject& ob, V3 p) {
   V3 a = ld3(ob.color_a), b = ld3(ob.color_b);
-  switch (ob.texture_kind) {
+  switch (ob.texture_kind & 0xffu) {
     case 1u:  // checker
       return (fmod(floor(p.x) + floor(p.y) + floor(p.z), 2.0) == 0.0) ? a : b;
     case 2u: {  // gradient
@@ -180,6 +180,15 @@ __device__ __forceinline__ V3 sample_texture(const DevObject& ob, V3 p) {
     default:
       return a;
   }
+}
+
+// `TransformPattern::sample_at` (src/graphics/patterns.rs:27-35) around the pattern: the
+// object-space point (w = 1) goes through the inverse pattern transform first.  The inverse
+// is formed once at scene upload with the reference's cofactor method; a singular transform
+// is stored as "no transform".
+__device__ __forceinline__ V3 sample_texture_at(const DevScene& S, const DevObject& ob, uint32_t obj, V3 objp) {
+  if (ob.texture_kind & 0x80000000u) objp = xform(S.pattern_inv + 12 * (size_t)obj, objp, 1.0);
+  return sample_texture(ob, objp);
 }
 
 // `LightingData::calculate` (src/scene/lighting.rs:40-78) without the refractive indices.

@@ -149,10 +149,17 @@ class Texture:
     """`Texture::{Solid, Pattern}` with the four patterns a scene file can name
     (src/scene/materials.rs:7-10, src/loader.rs:137-175)."""
 
-    __slots__ = ("kind", "a", "b")
+    __slots__ = ("kind", "a", "b", "transform")
 
-    def __init__(self, kind, a, b=BLACK):
+    def __init__(self, kind, a, b=BLACK, transform=None):
         self.kind, self.a, self.b = kind, rgb(*a), rgb(*b)
+        self.transform = transform  # None, or the Matrix4x4 of a `TransformPattern`
+
+    def with_transform(self, transform):
+        """`TransformPattern::new(pattern).with_transform(t)` (src/graphics/patterns.rs:12-25):
+        repeated calls multiply on the right."""
+        current = self.transform if self.transform is not None else Matrix4x4.identity()
+        return Texture(self.kind, self.a, self.b, current * transform)
 
     @staticmethod
     def solid(color):
@@ -227,6 +234,9 @@ class Material:
         m.texture_kind = self.texture.kind
         m.color_a[:] = self.texture.a
         m.color_b[:] = self.texture.b
+        if self.texture.transform is not None:
+            m.pattern_transformed = 1
+            m.pattern_transform[:] = self.texture.transform.e
         m.ambient, m.diffuse, m.specular, m.shininess = self.ambient, self.diffuse, self.specular, self.shininess
         m.transparency, m.reflectivity, m.refractivity = self.transparency, self.reflectivity, self.refractivity
         return m

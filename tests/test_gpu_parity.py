@@ -355,3 +355,27 @@ def test_large_coordinates(rtk, dev, oracle):
     camera = rtk.Camera(160, 90, rtk.PI / 3)
     camera.transform = M.look_at(rtk.point(3000.0, -195.0, 1494.0), rtk.point(3000.0, -200.0, 1509.0), rtk.vec3(0, 1, 0))
     check_against_oracle(dev, oracle, scene, camera, "large coordinates")
+
+
+def test_transformed_patterns(rtk, dev, oracle):
+    """`TransformPattern` around each pattern kind (src/graphics/patterns.rs:7-35), on spheres and
+    planes, opaque (shading kernel) and with a reflective object in the scene (single kernel);
+    a singular pattern transform samples the untransformed point."""
+    M = rtk.Matrix4x4
+    mat = rtk.Material.default()
+    T = rtk.Texture
+    for reflective in (0.0, 0.5):
+        scene = rtk.Scene()
+        scene.add_light(rtk.PointLight(rtk.vec3(-10, 10, -10), rtk.rgb(0.8, 0.8, 0.8)))
+        scene.add_light(rtk.PointLight(rtk.vec3(6, 12, -3), rtk.rgb(0.3, 0.3, 0.3)))
+        scene.add_object(rtk.Plane().with_material(mat.with_reflective(reflective).with_pattern(
+            T.checker(rtk.WHITE, rtk.rgb(0.1, 0.1, 0.1)).with_transform(M.rotate_y(0.5) * M.scale(0.37, 0.37, 0.37)))))
+        scene.add_object(rtk.Sphere().with_transform(M.translate(-1.6, 1, 0.5)).with_material(mat.with_pattern(
+            T.striped(rtk.rgb(1, 0.2, 0.2), rtk.rgb(0.2, 0.2, 1)).with_transform(M.rotate_z(0.7) * M.scale(0.2, 0.2, 0.2)))))
+        scene.add_object(rtk.Sphere().with_transform(M.translate(0.6, 1, 0) * M.scale(1, 0.6, 1)).with_material(mat.with_pattern(
+            T.gradient(rtk.rgb(0, 1, 0), rtk.rgb(1, 0, 1)).with_transform(M.translate(0.3, 0, 0) * M.shear(0.5, 0, 0, 0, 0.2, 0)))))
+        scene.add_object(rtk.Sphere().with_transform(M.translate(2.4, 0.7, -0.8) * M.scale(0.7, 0.7, 0.7)).with_material(mat.with_pattern(
+            T.ring(rtk.rgb(1, 1, 0), rtk.rgb(0, 0.3, 0.3)).with_transform(M.scale(0.15, 1, 0.15)).with_transform(M.rotate_x(1.0)))))
+        scene.add_object(rtk.Sphere().with_transform(M.translate(-0.4, 0.4, -1.6) * M.scale(0.4, 0.4, 0.4)).with_material(mat.with_pattern(
+            T.striped(rtk.WHITE, rtk.BLACK).with_transform(M.scale(0, 1, 1)))))
+        check_against_oracle(dev, oracle, scene, rtk.Camera(480, 270, rtk.PI / 3), f"transformed patterns, reflective={reflective}")

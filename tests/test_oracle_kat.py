@@ -381,3 +381,30 @@ def test_packed_scene_loads(rtk, golden_dir):  # loader.rs:206-212
     assert scene.lights[0].position == (-10.0, 10.0, -10.0, 0.0)  # vec3: w = 0
     assert scene.nodes[0].kind == rtk.abi.RTK_PLANE and scene.nodes[0].material.reflectivity == 0.7
     assert scene.nodes[2].transform.e == [0.33, 0, 0, -1.5, 0, 0.33, 0, 0.33, 0, 0, 0.33, -0.75, 0, 0, 0, 1]
+
+
+# ---- TransformPattern (src/graphics/patterns.rs:7-35) ------------------------------------------
+# The reference's tests hold no known answer for a transformed pattern: parity unpinned.  The
+# cases below state what its three lines of code do (inverse * point, then the inner pattern)
+# on inputs whose results can be read off by hand.
+def test_transform_pattern_scales_translates_and_ignores_singular(rtk, oracle):
+    M = rtk.Matrix4x4
+    stripes = rtk.Texture.striped(rtk.WHITE, rtk.BLACK)
+
+    def sample(texture, p):
+        return tuple(oracle.texture_sample_at(rtk.Material.default().with_pattern(texture), p))
+
+    assert sample(stripes, rtk.point(1.5, 0, 0)) == rtk.BLACK
+    assert sample(stripes.with_transform(M.scale(2, 2, 2)), rtk.point(1.5, 0, 0)) == rtk.WHITE   # 0.75 -> floor 0
+    assert sample(stripes.with_transform(M.scale(2, 2, 2)), rtk.point(2.5, 0, 0)) == rtk.BLACK   # 1.25 -> floor 1
+    assert sample(stripes.with_transform(M.translate(0.5, 0, 0)), rtk.point(0.25, 0, 0)) == rtk.BLACK  # -0.25 -> floor -1
+    # with_transform multiplies on the right: translate first, then scale, as one matrix T * S
+    both = stripes.with_transform(M.translate(1, 0, 0)).with_transform(M.scale(2, 1, 1))
+    assert both.transform == M.translate(1, 0, 0) * M.scale(2, 1, 1)
+    assert sample(both, rtk.point(2.5, 0, 0)) == rtk.WHITE    # (2.5 - 1) / 2 = 0.75
+    assert sample(both, rtk.point(3.5, 0, 0)) == rtk.BLACK    # 1.25
+    # a singular transform leaves the point as it is (`if let Ok(inverse)`)
+    assert sample(stripes.with_transform(M.scale(0, 1, 1)), rtk.point(1.5, 0, 0)) == rtk.BLACK
+    grad = rtk.Texture.gradient(rtk.rgb(0, 0, 0), rtk.rgb(1, 1, 1)).with_transform(M.rotate_y(rtk.PI / 2))
+    got = sample(grad, rtk.point(0, 0, -0.25))   # inverse rotation takes z = -0.25 to x = 0.25
+    assert all(abs(c - 0.25) < 1e-12 for c in got)

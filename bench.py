@@ -114,28 +114,22 @@ def main():
         if world > 1:
             tdist.barrier()
 
-    kernel_ms, rays_ms = [], []
-    local_rays = 0
-
-    def step(record):
-        nonlocal local_rays
-        renderer.frame()
-        if record:
-            st = dev.stats()  # waits for this step's kernel; HIP events around the trace kernel
-            kernel_ms.append(st.kernel_ms)
-            rays_ms.append(st.rays_ms)
-            local_rays = st.rays
-
+    # Steps are queued back to back; nothing waits on a frame inside the timed region.  The
+    # library keeps HIP-event times of its last 64 launches (events on the launch stream),
+    # read after the region; the ray counters are those of the last frame (every frame of a
+    # fixed scene traces the same rays).
     for _ in range(args.warmup):
-        step(False)
+        renderer.frame()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        renderer.frame()
     torch.cuda.synchronize()
     if world > 1:
         tdist.barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms, rays_ms = dev.timing_history(args.steps)
+    local_rays = dev.stats().rays
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     rays = torch.tensor([local_rays], dtype=torch.float64, device="cuda")

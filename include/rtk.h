@@ -203,6 +203,14 @@ int rtk_untile(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t world
 /* Waits for the stream of the last render and returns its ray counts and kernel time. */
 int rtk_get_stats(rtk_context* ctx, rtk_stats* stats);
 
+/* Kernel times (as rtk_stats.kernel_ms / rays_ms) of the most recent rtk_render_device /
+ * rtk_trace_rays calls on this context, oldest first: lets a caller queue many frames
+ * without waiting on each and read their times afterwards.  Fills min(capacity, calls so
+ * far, RTK_TIMING_HISTORY) entries, waits for the newest of them, and returns how many it
+ * filled (or an rtk_status < 0).  No counterpart in the reference. */
+#define RTK_TIMING_HISTORY 64
+int rtk_get_timing_history(rtk_context* ctx, uint32_t capacity, double* kernel_ms, double* rays_ms);
+
 /* Thread-local description of the last failure on this thread ("" if none). */
 const char* rtk_last_error(void);
 

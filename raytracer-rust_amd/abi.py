@@ -24,6 +24,7 @@ RTK_TEX_STRIPED = 4
 
 RTK_REFERENCE_MAX_DEPTH = 5
 RTK_MAX_DEPTH_LIMIT = 8
+RTK_TIMING_HISTORY = 64
 RTK_TILE_W = 32
 RTK_TILE_H = 8
 
@@ -130,6 +131,7 @@ SYMBOLS = {
          C.c_void_p],
     ),
     "rtk_get_stats": (C.c_int, [C.c_void_p, C.POINTER(rtk_stats)]),
+    "rtk_get_timing_history": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rtk_last_error": (C.c_char_p, []),
     "rtk_version": (C.c_char_p, []),
 }

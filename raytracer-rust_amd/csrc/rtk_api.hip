@@ -161,11 +161,13 @@ struct rtk_scene_handle {
 struct rtk_context {
   int device = -1;
   hipStream_t stream = nullptr;
-  hipEvent_t ev_start = nullptr, ev_rays = nullptr, ev_stop = nullptr;  // ev_rays: end of the ray kernels
+  // One (start, end of the ray kernels, stop) event triple per recent call, used round-robin, so
+  // that a caller can render many frames back to back and read their kernel times afterwards.
+  hipEvent_t ev_start[RTK_TIMING_HISTORY] = {}, ev_rays[RTK_TIMING_HISTORY] = {}, ev_stop[RTK_TIMING_HISTORY] = {};
+  bool ev_split[RTK_TIMING_HISTORY] = {};  // ev_rays was recorded by the call that used the slot
+  uint64_t n_timed = 0;                    // calls that recorded a triple; the newest sits in slot (n_timed - 1) % N
   rtk::DevCounters* d_counters = nullptr;
   hipStream_t last_stream = nullptr;
-  bool have_timing = false;
-  bool split_timing = false;  // ev_rays was recorded by the last call
   // staging for rtk_render (host-buffer variant)
   float* d_rgb = nullptr;
   uint8_t* d_rgba8 = nullptr;
@@ -240,6 +242,16 @@ uint64_t rtk_compact_pixels(uint32_t width, uint32_t height, uint32_t rank, uint
   return rtk_tiles_for_rank(width, height, rank, world) * (uint64_t)(RTK_TILE_W * RTK_TILE_H);
 }
 
+static hipError_t create_timing_events(rtk_context* ctx) {
+  for (int i = 0; i < RTK_TIMING_HISTORY; ++i) {
+    hipError_t e;
+    if ((e = hipEventCreate(&ctx->ev_start[i])) != hipSuccess || (e = hipEventCreate(&ctx->ev_rays[i])) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_stop[i])) != hipSuccess)
+      return e;
+  }
+  return hipSuccess;
+}
+
 int rtk_create(int device_id, rtk_context** out) {
   if (!out) return fail(RTK_ERR_INVALID, "rtk_create: null out pointer");
   *out = nullptr;
@@ -256,8 +268,7 @@ int rtk_create(int device_id, rtk_context** out) {
   if (!ctx) return fail(RTK_ERR_NOMEM, "rtk_create: out of host memory");
   ctx->device = device_id;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipEventCreate(&ctx->ev_start)) != hipSuccess || (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
-      (e = hipEventCreate(&ctx->ev_rays)) != hipSuccess ||
+      (e = create_timing_events(ctx)) != hipSuccess ||
       (e = hipMalloc((void**)&ctx->d_counters, sizeof(rtk::DevCounters) * rtk::kCounterShards)) != hipSuccess ||
       (e = hipMemset(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards)) != hipSuccess) {
     rtk_destroy(ctx);
@@ -277,9 +288,11 @@ void rtk_destroy(rtk_context* ctx) {
   if (ctx->opaque.hit_obj) (void)hipFree(ctx->opaque.hit_obj);
   if (ctx->opaque.hit_t) (void)hipFree(ctx->opaque.hit_t);
   if (ctx->opaque.shadow) (void)hipFree(ctx->opaque.shadow);
-  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
-  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
-  if (ctx->ev_rays) (void)hipEventDestroy(ctx->ev_rays);
+  for (int i = 0; i < RTK_TIMING_HISTORY; ++i) {
+    if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
+    if (ctx->ev_rays[i]) (void)hipEventDestroy(ctx->ev_rays[i]);
+    if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
+  }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -636,29 +649,40 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
   }
   RTK_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, st));
   RTK_HIP(rtk::launch_prep_primary(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball, scene->d_prim_cluster));
-  RTK_HIP(hipEventRecord(ctx->ev_start, st));  // the per-camera record kernel (microseconds) stays outside
-  ctx->split_timing = opaque;
+  const int slot = (int)(ctx->n_timed % RTK_TIMING_HISTORY);
+  RTK_HIP(hipEventRecord(ctx->ev_start[slot], st));  // the per-camera record kernel (microseconds) stays outside
+  ctx->ev_split[slot] = opaque;
   if (opaque)
     RTK_HIP(rtk::launch_render_opaque(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball, scene->d_prim_cluster, t,
-                                      ctx->opaque, ctx->d_counters, ctx->ev_rays));
+                                      ctx->opaque, ctx->d_counters, ctx->ev_rays[slot]));
   else
     RTK_HIP(rtk::launch_render(st, scene->dev, cam, scene->d_prim, scene->d_prim_cluster, t, ctx->d_counters));
-  RTK_HIP(hipEventRecord(ctx->ev_stop, st));
+  RTK_HIP(hipEventRecord(ctx->ev_stop[slot], st));
   ctx->last_stream = st;
-  ctx->have_timing = true;
+  ++ctx->n_timed;
+  return RTK_OK;
+}
+
+// Kernel times of the call that used timing slot `slot`; the caller has synchronised on it.
+static int slot_times(rtk_context* ctx, int slot, double* kernel_ms, double* rays_ms) {
+  float ms = 0.f;
+  RTK_HIP(hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
+  float rms = ms;
+  if (ctx->ev_split[slot]) RTK_HIP(hipEventElapsedTime(&rms, ctx->ev_start[slot], ctx->ev_rays[slot]));
+  *kernel_ms = ms;
+  *rays_ms = rms;
   return RTK_OK;
 }
 
 int rtk_get_stats(rtk_context* ctx, rtk_stats* stats) {
   if (!ctx || !stats) return fail(RTK_ERR_INVALID, "rtk_get_stats: null argument");
   std::memset(stats, 0, sizeof *stats);
-  if (!ctx->have_timing) return RTK_OK;
+  if (ctx->n_timed == 0) return RTK_OK;
   RTK_HIP(hipSetDevice(ctx->device));
-  RTK_HIP(hipEventSynchronize(ctx->ev_stop));
-  float ms = 0.f;
-  RTK_HIP(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
-  float rays_ms = ms;
-  if (ctx->split_timing) RTK_HIP(hipEventElapsedTime(&rays_ms, ctx->ev_start, ctx->ev_rays));
+  const int slot = (int)((ctx->n_timed - 1) % RTK_TIMING_HISTORY);
+  RTK_HIP(hipEventSynchronize(ctx->ev_stop[slot]));
+  const int rc = slot_times(ctx, slot, &stats->kernel_ms, &stats->rays_ms);
+  if (rc != RTK_OK) return rc;
   rtk::DevCounters shards[rtk::kCounterShards];
   RTK_HIP(hipMemcpyAsync(shards, ctx->d_counters, sizeof shards, hipMemcpyDeviceToHost, ctx->last_stream));
   RTK_HIP(hipStreamSynchronize(ctx->last_stream));
@@ -668,9 +692,24 @@ int rtk_get_stats(rtk_context* ctx, rtk_stats* stats) {
     stats->rays_secondary += c.rays_secondary;
     stats->exact_tests += c.exact_tests;
   }
-  stats->kernel_ms = ms;
-  stats->rays_ms = rays_ms;
   return RTK_OK;
+}
+
+int rtk_get_timing_history(rtk_context* ctx, uint32_t capacity, double* kernel_ms, double* rays_ms) {
+  if (!ctx || !kernel_ms || !rays_ms) return fail(RTK_ERR_INVALID, "rtk_get_timing_history: null argument");
+  uint64_t n = ctx->n_timed < RTK_TIMING_HISTORY ? ctx->n_timed : RTK_TIMING_HISTORY;
+  if (n > capacity) n = capacity;
+  if (n == 0) return 0;
+  RTK_HIP(hipSetDevice(ctx->device));
+  RTK_HIP(hipEventSynchronize(ctx->ev_stop[(ctx->n_timed - 1) % RTK_TIMING_HISTORY]));
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint64_t call = ctx->n_timed - n + i;  // oldest of the n first
+    const int slot = (int)(call % RTK_TIMING_HISTORY);
+    RTK_HIP(hipEventSynchronize(ctx->ev_stop[slot]));  // calls may have gone to different streams
+    const int rc = slot_times(ctx, slot, &kernel_ms[i], &rays_ms[i]);
+    if (rc != RTK_OK) return rc;
+  }
+  return (int)n;
 }
 
 int rtk_render(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camera, float* rgb_f32_out, uint8_t* rgba8_out,
@@ -725,10 +764,11 @@ int rtk_trace_rays(rtk_context* ctx, rtk_scene_handle* scene, const double* orig
   if (e == hipSuccess) e = hipMemcpyAsync(d_o, origins, n * 4 * sizeof(double), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_d, directions, n * 4 * sizeof(double), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, st);
-  ctx->split_timing = false;
-  if (e == hipSuccess) e = hipEventRecord(ctx->ev_start, st);
+  const int slot = (int)(ctx->n_timed % RTK_TIMING_HISTORY);
+  ctx->ev_split[slot] = false;
+  if (e == hipSuccess) e = hipEventRecord(ctx->ev_start[slot], st);
   if (e == hipSuccess) e = rtk::launch_trace_rays(st, scene->dev, d_o, d_d, n, d_c, ctx->d_counters);
-  if (e == hipSuccess) e = hipEventRecord(ctx->ev_stop, st);
+  if (e == hipSuccess) e = hipEventRecord(ctx->ev_stop[slot], st);
   if (e == hipSuccess) e = hipMemcpyAsync(colors_out, d_c, n * 3 * sizeof(double), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (d_o) (void)hipFree(d_o);
@@ -736,7 +776,7 @@ int rtk_trace_rays(rtk_context* ctx, rtk_scene_handle* scene, const double* orig
   if (d_c) (void)hipFree(d_c);
   if (e != hipSuccess) return fail_hip(e, "rtk_trace_rays");
   ctx->last_stream = st;
-  ctx->have_timing = true;
+  ++ctx->n_timed;
   return RTK_OK;
 }
 

@@ -138,6 +138,15 @@ class Device:
         _check(library().rtk_get_stats(self.ctx, C.byref(st)))
         return st
 
+    def timing_history(self, n=abi.RTK_TIMING_HISTORY):
+        """(kernel_ms, rays_ms) lists of the last `n` device renders (at most RTK_TIMING_HISTORY), oldest first."""
+        n = max(1, min(int(n), abi.RTK_TIMING_HISTORY))
+        k, r = (C.c_double * n)(), (C.c_double * n)()
+        got = library().rtk_get_timing_history(self.ctx, n, k, r)
+        if got < 0:
+            _check(got)
+        return list(k[:got]), list(r[:got])
+
     def render(self, scene, camera):
         """`Camera::render` through the host-buffer entry point; returns a Canvas."""
         s = scene.to_abi() if hasattr(scene, "to_abi") else scene

@@ -115,3 +115,28 @@ def test_render_on_a_caller_stream(rtk, dev):
     s.synchronize()
     torch.cuda.synchronize()
     assert torch.equal(rgb, want_rgb) and torch.equal(rgba, want_rgba)
+
+
+def test_timing_history_of_back_to_back_frames(rtk, dev):
+    """Frames queued without waiting; their kernel times are read afterwards, oldest first."""
+    scene, camera = rtk.synthetic.config("C2", 320, 180)
+    h = dev.upload(scene)
+    fresh = dev.timing_history(5)
+    for _ in range(70):  # more than the library keeps
+        dev.render_device(h, camera)
+    kernel_ms, rays_ms = dev.timing_history(5)
+    assert len(kernel_ms) == 5 and len(rays_ms) == 5
+    assert all(k > 0.0 for k in kernel_ms) and all(0.0 < r <= k for k, r in zip(kernel_ms, rays_ms))
+    st = dev.stats()
+    assert abs(st.kernel_ms - kernel_ms[-1]) < 1e-9 and abs(st.rays_ms - rays_ms[-1]) < 1e-9
+    everything, _ = dev.timing_history(1000)
+    assert len(everything) == rtk.abi.RTK_TIMING_HISTORY
+    assert len(fresh[0]) <= 5
+    # a scene with secondary rays runs rays and shading in one kernel: the two times coincide
+    scene_g, camera_g = rtk.synthetic.config("C2g", 160, 90)
+    hg = dev.upload(scene_g)
+    dev.render_device(hg, camera_g)
+    k, r = dev.timing_history(1)
+    assert k[0] > 0.0 and k[0] == r[0]
+    h.release()
+    hg.release()

@@ -40,7 +40,7 @@ struct StackEntry {
   int depth;
 };
 
-template <bool SECONDARY, bool PRIMARY_FILTER, int LB>
+template <bool SECONDARY, bool PRIMARY_FILTER, int LB, bool WIDE>
 __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restrict__ prim,
                                         const float4* __restrict__ prim_cluster, bool valid, V3 o,
                                         V3 d, unsigned& c_primary, unsigned& c_shadow, unsigned& c_secondary,
@@ -85,7 +85,7 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
     if (PRIMARY_FILTER && (!SECONDARY || iter == 0))
       closest_primary(S, prim, prim_cluster, have, ro, rd, best, c_exact);
     else
-      closest_general(S, have, ro, rd, best, c_exact);
+      closest_general<WIDE>(S, have, ro, rd, best, c_exact);
 
     const bool hit = have && best.obj != 0xffffffffu;
     if (have && !hit) color = color + scene_ambient * weight;  // trace_inner: miss -> ambient_color
@@ -151,7 +151,7 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
       }
     }
 
-    const bool in_shadow = shadow_sweeps<LB>(S, hit, over, c_shadow, c_exact);
+    const bool in_shadow = shadow_sweeps<LB, WIDE>(S, hit, over, c_shadow, c_exact);
 
     if (hit) {
       const DevObject& ob = S.objects[obj];
@@ -168,7 +168,7 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
 // `Camera::render` (src/scene/cameras.rs:72-85): ray generation (cameras.rs:52-69 with the
 // matrix inverse hoisted to the host), trace, and the framebuffer store
 // (src/graphics.rs:44-46, 59-74).
-template <bool SECONDARY, int LB>
+template <bool SECONDARY, int LB, bool WIDE>
 __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                         const float4* __restrict__ prim_cluster, RenderTarget T,
                                                         DevCounters* counters) {
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera
   const V3 dir = camera_ray_direction(C, x, y);  // cameras.rs:52-69
 
   unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
-  V3 color = trace_ray<SECONDARY, true, LB>(S, prim, prim_cluster, valid, origin, dir, c_primary, c_shadow, c_secondary, c_exact);
+  V3 color = trace_ray<SECONDARY, true, LB, WIDE>(S, prim, prim_cluster, valid, origin, dir, c_primary, c_shadow, c_secondary, c_exact);
 
   // ---- framebuffer store, transposed through LDS so that every wavefront writes whole
   // 128-byte (RGBA8) / 384-byte (FP32 RGB) tile rows
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera
 }
 
 // `Scene::trace` for caller-supplied rays (src/scene.rs:136-138): n x 4 doubles each.
-template <int LB>
+template <int LB, bool WIDE>
 __global__ void __launch_bounds__(kBlock) trace_rays_kernel(DevScene S, const double* __restrict__ origins,
                                                             const double* __restrict__ directions, uint64_t n,
                                                             double* __restrict__ colors, DevCounters* counters) {
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(kBlock) trace_rays_kernel(DevScene S, const do
     d = ld3(directions + 4 * i);
   }
   unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
-  V3 color = trace_ray<true, false, LB>(S, nullptr, nullptr, valid, o, d, c_primary, c_shadow, c_secondary, c_exact);
+  V3 color = trace_ray<true, false, LB, WIDE>(S, nullptr, nullptr, valid, o, d, c_primary, c_shadow, c_secondary, c_exact);
   if (valid) {
     colors[3 * i + 0] = color.x;
     colors[3 * i + 1] = color.y;
@@ -335,15 +335,19 @@ __global__ void __launch_bounds__(kBlock) untile_kernel(uint32_t width, uint32_t
 // ------------------------------------------------------------------------------------
 // launch wrappers (called from rtk_api.hip)
 
-template <bool SECONDARY>
+// WIDE kernels carry the sphere-per-lane sweep of opened clusters; scenes below kWideScene
+// spheres never take it.
+constexpr uint32_t kWideScene = 256;
+
+template <bool WIDE>
 static hipError_t launch_render_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, const DevCamera& C,
                                    const float4* prim, const float4* prim_cluster, const RenderTarget& T,
                                    DevCounters* counters) {
   switch (lb) {
-    case 1: hipLaunchKernelGGL((render_kernel<SECONDARY, 1>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
-    case 2: hipLaunchKernelGGL((render_kernel<SECONDARY, 2>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
-    case 4: hipLaunchKernelGGL((render_kernel<SECONDARY, 4>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
-    default: hipLaunchKernelGGL((render_kernel<SECONDARY, 8>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
+    case 1: hipLaunchKernelGGL((render_kernel<true, 1, WIDE>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
+    case 2: hipLaunchKernelGGL((render_kernel<true, 2, WIDE>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
+    case 4: hipLaunchKernelGGL((render_kernel<true, 4, WIDE>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
+    default: hipLaunchKernelGGL((render_kernel<true, 8, WIDE>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
   }
   return hipGetLastError();
 }
@@ -369,23 +373,30 @@ hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, 
   if (T.n_local_tiles == 0) return hipSuccess;
   dim3 grid(T.n_local_tiles);
   const int lb = light_batch_for(S.n_lights);
-  if (S.any_secondary) return launch_render_lb<true>(lb, grid, st, S, C, prim, prim_cluster, T, counters);
+  if (S.n_spheres >= kWideScene) return launch_render_lb<true>(lb, grid, st, S, C, prim, prim_cluster, T, counters);
   return launch_render_lb<false>(lb, grid, st, S, C, prim, prim_cluster, T, counters);
+}
+
+template <bool WIDE>
+static hipError_t launch_trace_rays_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, const double* origins,
+                                       const double* directions, uint64_t n, double* colors, DevCounters* counters) {
+  switch (lb) {
+    case 1: hipLaunchKernelGGL((trace_rays_kernel<1, WIDE>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
+    case 2: hipLaunchKernelGGL((trace_rays_kernel<2, WIDE>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
+    case 4: hipLaunchKernelGGL((trace_rays_kernel<4, WIDE>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
+    default: hipLaunchKernelGGL((trace_rays_kernel<8, WIDE>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_trace_rays(hipStream_t st, const DevScene& S, const double* origins, const double* directions, uint64_t n,
                              double* colors, DevCounters* counters) {
   if (n == 0) return hipSuccess;
   dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-  switch (light_batch_for(S.n_lights)) {
-    case 1: hipLaunchKernelGGL((trace_rays_kernel<1>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
-    case 2: hipLaunchKernelGGL((trace_rays_kernel<2>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
-    case 4: hipLaunchKernelGGL((trace_rays_kernel<4>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
-    default: hipLaunchKernelGGL((trace_rays_kernel<8>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
-  }
-  return hipGetLastError();
+  const int lb = light_batch_for(S.n_lights);
+  if (S.n_spheres >= kWideScene) return launch_trace_rays_lb<true>(lb, grid, st, S, origins, directions, n, colors, counters);
+  return launch_trace_rays_lb<false>(lb, grid, st, S, origins, directions, n, colors, counters);
 }
-
 hipError_t launch_untile(hipStream_t st, uint32_t width, uint32_t height, uint32_t world, uint64_t slot_pixels,
                          const float* rgb_c, float* rgb_f, const uint8_t* px_c, uint8_t* px_f) {
   const uint32_t tiles_x = (width + 31u) / 32u, tiles_y = (height + 7u) / 8u;

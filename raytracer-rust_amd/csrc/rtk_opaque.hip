@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(kBlock, 4) shadow_general_kernel(DevScene S, D
   V3 p = {0, 0, 0};
   if (hit) p = over_point(S, C, px, obj, B.hit_t[px.local]);
   unsigned rays = 0, n_exact = 0;
-  const bool in_shadow = shadow_sweeps<LB>(S, hit, p, rays, n_exact);
+  const bool in_shadow = shadow_sweeps<LB, false>(S, hit, p, rays, n_exact);
   B.shadow[px.local] = (uint8_t)((in_shadow ? 0x80u : 0u) | rays);
   n_exact = wave_sum(n_exact);
   if ((threadIdx.x & 63u) == 0) atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);

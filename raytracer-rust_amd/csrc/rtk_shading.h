@@ -297,6 +297,11 @@ __device__ __forceinline__ float wave_max_f(float v) {
 }
 __device__ __forceinline__ float wave_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 
+// value of lane `src` (wavefront-uniform index) in every lane, through an SGPR: no memory round trip
+__device__ __forceinline__ float lane_value(float v, uint32_t src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)src));
+}
+
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);

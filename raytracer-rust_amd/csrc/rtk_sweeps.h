@@ -18,6 +18,11 @@
 
 namespace rtk {
 
+// An opened cluster is swept sphere-per-lane when at most this many of the 64 rays reach it
+// (and it holds enough spheres for 64 lanes to be worth occupying).  Kernels are built with
+// and without that path (WIDE): small scenes never need it and run faster without its code.
+constexpr int kTransposeBelow = 24;
+
 // ------------------------------------------------------------------------------------
 // Camera rays: all rays of a frame leave from the camera origin, so the per-sphere part
 // of the test is hoisted into the record {L = c - o, CC = |L|^2 (1 - slack) - R'^2}.
@@ -83,7 +88,7 @@ __device__ __forceinline__ void sweep_primary(const DevScene& S, const float4* _
 // w in [0, 1]).  For a cluster ball {C, Rc} around its members' balls, with s_C = (p - C).g:
 //     dist(C, line) <= Rc + r_max |rho| max(Rc - s_C, 0) + r_max^3 rho^2 / 2
 // is necessary for any member to be touched (r_max = largest sphere radius of the scene).
-template <int NR, typename ExactFn, typename DoneFn>
+template <int NR, bool WIDE, typename ExactFn, typename DoneFn>
 __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, float px, float py, float pz,
                                              const float (&gx)[NR], const float (&gy)[NR], const float (&gz)[NR],
                                              const float (&rho)[NR], float thr, ExactFn&& exact, DoneFn&& done) {
@@ -116,7 +121,57 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
       }
       reach = active && pass;
     }
-    if (!__any(reach)) continue;
+    const unsigned long long reach_mask = __builtin_amdgcn_ballot_w64(reach);
+    if (reach_mask == 0ull) continue;
+    if (WIDE && __builtin_popcountll(reach_mask) <= kTransposeBelow && S.n_spheres_grouped - first >= 32u) {
+      // Few rays reach this cluster (incoherent rays): turn the loop around.  Every lane takes
+      // ONE sphere of the cluster; the reaching rays are broadcast one after the other and
+      // tested against all 64 spheres at once; each ray's owner keeps the set of spheres that
+      // passed and re-evaluates those per light before the f64 test.
+      const uint32_t lane = threadIdx.x & 63u;
+      const float4 mine = S.sph_filter[first + lane];       // padded to kBundle: always in range
+      const bool real = first + lane < S.n_spheres;         // padding repeats the last sphere
+      unsigned long long cand = 0ull;
+      for (unsigned long long rm = reach_mask; rm != 0ull; rm &= rm - 1ull) {
+        const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(rm));
+        const float qx = lane_value(px, src), qy = lane_value(py, src), qz = lane_value(pz, src);
+        const float qthr = lane_value(thr, src);
+        const float ux = qx - mine.x, uy = qy - mine.y, uz = qz - mine.z;
+        const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+        const float cf = __builtin_fmaf(uu, kKappa, -mine.w);
+        float m = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const float h = __builtin_fmaf(uz, lane_value(gz[r], src),
+                                         __builtin_fmaf(uy, lane_value(gy[r], src),
+                                                        __builtin_fmaf(ux, lane_value(gx[r], src), mine.w * lane_value(rho[r], src))));
+          m = fmaxf(m, __builtin_fmaf(h, h, -cf));
+        }
+        const unsigned long long kept = __builtin_amdgcn_ballot_w64(real && m >= qthr);
+        if (lane == src) cand = kept;
+      }
+      // every lane now works through its own candidates; lanes run different spheres side by side
+      while (__any(cand != 0ull)) {
+        if (cand != 0ull) {
+          const uint32_t b = (uint32_t)__builtin_ctzll(cand);
+          cand &= cand - 1ull;
+          const float4 c = S.sph_filter[first + b];
+          const float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
+          const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+          const float cf = __builtin_fmaf(uu, kKappa, -c.w);
+          uint32_t mask = 0;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const float h = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], __builtin_fmaf(ux, gx[r], c.w * rho[r])));
+            if (__builtin_fmaf(h, h, -cf) >= thr) mask |= 1u << r;
+          }
+          if (mask) exact(S.sph_object[first + b], mask);
+          if (active && done()) active = false, cand = 0ull;
+        }
+      }
+      wave_live = __any(active);
+      continue;
+    }
     const uint32_t end = min(first + (uint32_t)kBundle, S.n_spheres_grouped);
     for (uint32_t j = first; j < end; j += kGroup) {
       float4 q[kGroup];
@@ -166,7 +221,7 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
 // Shadow test for one shading point: `Scene::is_shadowed` (src/scene.rs:208-225).
 // Lights are swept in batches of LB fused rays; the reference stops at the first blocked
 // light, so `n_rays` = index of the first blocked light + 1 (or the light count).
-template <int LB>
+template <int LB, bool WIDE>
 __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3 p, unsigned& n_rays,
                                               unsigned& n_exact) {
   bool in_shadow = false;
@@ -226,7 +281,7 @@ __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3
       }
     };
     auto done = [&]() { return (occl & 1u) != 0; };
-    sweep_filter<LB>(S, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done);
+    sweep_filter<LB, WIDE>(S, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done);
     if (need) {
       occl &= (1u << nb) - 1u;
       if (occl) {
@@ -245,6 +300,7 @@ __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3
 // ------------------------------------------------------------------------------------
 // Closest hit of a general ray (origin o, direction d with w = 0, not necessarily unit):
 // `Scene::intersect` + `HitList::closest_hit` (src/scene.rs:156-169, 325-340).
+template <bool WIDE>
 __device__ __forceinline__ void closest_general(const DevScene& S, bool active, V3 o, V3 d, Closest& best,
                                                 unsigned& n_exact) {
   closest_init(best);
@@ -270,7 +326,7 @@ __device__ __forceinline__ void closest_general(const DevScene& S, bool active, 
   };
   auto done = [&]() { return false; };
   bool live = active;
-  sweep_filter<1>(S, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done);
+  sweep_filter<1, WIDE>(S, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done);
 }
 
 // Closest hit of a camera ray (unit direction, shared origin).

@@ -379,3 +379,31 @@ def test_transformed_patterns(rtk, dev, oracle):
         scene.add_object(rtk.Sphere().with_transform(M.translate(-0.4, 0.4, -1.6) * M.scale(0.4, 0.4, 0.4)).with_material(mat.with_pattern(
             T.striped(rtk.WHITE, rtk.BLACK).with_transform(M.scale(0, 1, 1)))))
         check_against_oracle(dev, oracle, scene, rtk.Camera(480, 270, rtk.PI / 3), f"transformed patterns, reflective={reflective}")
+
+
+def test_large_scene_with_secondary_rays(rtk, dev, oracle):
+    """400 and 1000 spheres, a quarter of them glass, reflective floor: reflected and refracted
+    rays leave a wavefront in all directions, so opened clusters are swept sphere-per-lane."""
+    for n, w, h in ((400, 192, 108), (1000, 128, 72)):
+        scene = rtk.synthetic.make_scene(n, True, 3, 4242 + n, glass=True)
+        camera = rtk.synthetic.make_camera(n, w, h)
+        c = check_against_oracle(dev, oracle, scene, camera, f"{n} spheres with glass")
+        assert c.stats.rays_secondary > w * h
+
+
+def test_random_rays_in_a_large_scene(rtk, dev, oracle):
+    """`Scene::trace` for 2048 unrelated rays through 600 spheres (w = 0 and w = 1 lights)."""
+    scene = rtk.synthetic.make_scene(600, True, 2, 99, glass=True)
+    scene.lights[1] = rtk.PointLight(rtk.point(4.0, 30.0, -6.0), rtk.rgb(0.5, 0.5, 0.5))
+    rng = np.random.default_rng(17)
+    n = 2048
+    o = np.concatenate([rng.uniform(-15, 15, (n, 1)), rng.uniform(0.5, 12, (n, 1)), rng.uniform(-5, 35, (n, 1)), np.ones((n, 1))], axis=1)
+    d = np.concatenate([rng.normal(size=(n, 3)), np.zeros((n, 1))], axis=1)
+    d[:, 1] -= 0.5
+    d[:, :3] /= np.linalg.norm(d[:, :3], axis=1, keepdims=True)
+    h = dev.upload(scene)
+    got = dev.trace(h, o, d)
+    want = np.array([oracle.trace(scene, tuple(o[i]), tuple(d[i])) for i in range(n)])
+    err = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+    assert (err.max(axis=1) > 1e-9).sum() <= 2, f"max {err.max():.3e}"
+    h.release()

@@ -176,7 +176,7 @@ def main():
             "pct_fp32_valu_peak": 100.0 * (frame_rays * fpr * args.steps / elapsed / 1e12) / (PEAK_FP32_TFLOPS * world),
             "roofline": {
                 "bound": "valu",
-                "kernel": "trace_uniform_kernel (camera + shadow rays, rank 0)",
+                "kernel": measured.get("kernel") or "dominant ray kernel (rank 0)",
                 "achieved": achieved,
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
@@ -188,7 +188,8 @@ def main():
                 "all_kernels_ms": avg_kernel_ms,
                 "measured_valu_issue_util": measured.get("valu_issue_util"),
                 "note": "achieved = algorithmic flops of the reference's sweep (26 per ray-sphere test, 8 per ray-plane "
-                        "test, every ray against every object) / HIP-event time of the ray kernel. The kernel culls "
+                        "test, every ray against every object) / HIP-event time of the kernel that traces the rays "
+                        "(for up to 4 lights it also shades and stores: kernel_ms = all_kernels_ms). The kernel culls "
                         "whole clusters of spheres per wavefront and executes far fewer instructions than that count, "
                         "so the fraction exceeds 1; measured_valu_issue_util (rocprofv3 PMC, profiles/) is the share of "
                         "SIMD issue cycles the kernel really uses",

@@ -1,15 +1,16 @@
 // rtk_opaque.hip -- the render path for scenes without reflective or transparent
-// materials (every throughput configuration): lean kernels instead of one.
+// materials (every throughput configuration).  One pixel per lane, one 8x8 patch per
+// wavefront, one 32x8 tile per workgroup.
 //
-//   trace_uniform_kernel  (every light has w = 0) one pixel per lane: the camera ray, then
-//                    the shadow rays of its hit towards all lights; writes the hit
-//                    (object, t), the reference's shadow flag and its shadow-ray count
+//   render_uniform_kernel<4>  every light has w = 0, at most 4 lights: camera ray, the
+//                    shadow rays of its hit towards all lights, shading and the store, in
+//                    one kernel; nothing but the framebuffer crosses HBM
+//   trace_uniform_kernel<8>   every light has w = 0, 5..64 lights in batches of 8: camera
+//                    and shadow rays; writes the hit (object, t), the reference's shadow
+//                    flag and its shadow-ray count (13 bytes per pixel) for shade_kernel
 //   primary_kernel + shadow_general_kernel   the same in two kernels when some light has w != 0
 //   shade_kernel     rebuilds LightingData, samples the texture, sums Phong over the
 //                    lights and stores FP32 RGB + RGBA8 (transposed through LDS)
-//
-// Only 13 bytes per pixel of intermediate state cross HBM between the ray kernel and the
-// shading kernel; the f64 shading state is rebuilt where it is needed.
 //
 // Arithmetic of the decisions is the same as in the single-kernel path (rtk_kernels.hip):
 // conservative FP32 tests decide which (ray, object) pairs are looked at, then the
@@ -448,33 +449,25 @@ __global__ void __launch_bounds__(kBlock, 4) shadow_general_kernel(DevScene S, D
 }
 
 // ------------------------------------------------------------------------------------
-// Kernel 3: `apply_lighting` (src/scene.rs:172-205) for opaque materials and the store.
-__global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, RenderTarget T, OpaqueBuffers B,
-                                                      DevCounters* counters) {
-  __shared__ float s_rgb[768];
-  __shared__ uint32_t s_px[256];
-  const uint32_t k = blockIdx.x;
-  const PixelRef px = pixel_ref(T, C, k);
-  const V3 ambient = ld3(S.ambient);
-  V3 color = {0, 0, 0};
-  unsigned n_shadow = 0;
-  if (px.valid) {
-    color = ambient;  // a miss, or trace_inner at depth >= MAX_DEPTH, returns ambient_color
-    const uint32_t obj = B.hit_obj[px.local];
-    if (obj != 0xffffffffu) {
-      const uint8_t sh = B.shadow[px.local];
-      const bool in_shadow = (sh & 0x80u) != 0;
-      n_shadow = sh & 0x7fu;
-      const DevObject& ob = S.objects[obj];
-      const V3 d = camera_ray_direction(C, px.x, px.y);
-      const HitGeom g = lighting_data(ob, ld3(C.origin), d, B.hit_t[px.local]);
-      const V3 tex = sample_texture_at(S, ob, obj, g.objp);
-      V3 surface = ambient;
-      for (uint32_t l = 0; l < S.n_lights; ++l)
-        surface = surface + phong_lighting(S.lights[l], ob, tex, g.over, g.eye, g.normal, in_shadow);
-      color = surface;  // the reflected and refracted parts are BLACK for these materials
-    }
-  }
+// `apply_lighting` (src/scene.rs:172-205) for a hit on an opaque material: the reflected and
+// refracted parts are BLACK, what is left is ambient + the Phong sum over the lights.
+__device__ __forceinline__ V3 shade_hit(const DevScene& S, const DevCamera& C, const PixelRef& px, uint32_t obj, double t,
+                                        bool in_shadow) {
+  const DevObject& ob = S.objects[obj];
+  const V3 d = camera_ray_direction(C, px.x, px.y);
+  const HitGeom g = lighting_data(ob, ld3(C.origin), d, t);
+  const V3 tex = sample_texture_at(S, ob, obj, g.objp);
+  V3 surface = ld3(S.ambient);
+  for (uint32_t l = 0; l < S.n_lights; ++l)
+    surface = surface + phong_lighting(S.lights[l], ob, tex, g.over, g.eye, g.normal, in_shadow);
+  return surface;
+}
+
+// Framebuffer store of one 32x8 tile (local tile k), transposed through LDS so that every
+// wavefront writes whole 128-byte (RGBA8) / 384-byte (FP32 RGB) tile rows
+// (src/graphics.rs:44-46, 59-74).  All 256 threads of the workgroup call it.
+__device__ __forceinline__ void store_tile(const DevCamera& C, const RenderTarget& T, uint32_t k, V3 color, float* s_rgb,
+                                           uint32_t* s_px) {
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t lx = (wave << 3) | (lane & 7u), ly = lane >> 3;
   const uint32_t slot = ly * 32u + lx;
@@ -483,34 +476,85 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, 
   s_rgb[slot * 3 + 2] = (float)color.z;
   s_px[slot] = cast_u8(color.x) | (cast_u8(color.y) << 8) | (cast_u8(color.z) << 16) | 0xff000000u;
   __syncthreads();
-  {
-    const uint32_t tile = k * T.world + T.rank;
-    const uint32_t tx = tile % T.tiles_x, ty = tile / T.tiles_x;
-    const uint32_t rx = threadIdx.x & 31u, ry = threadIdx.x >> 5;
-    const uint32_t gx = tx * 32u + rx, gy = ty * 8u + ry;
-    if (T.rgba8) {
-      uint32_t* out = reinterpret_cast<uint32_t*>(T.rgba8);
-      if (T.compact)
-        out[(size_t)k * 256u + threadIdx.x] = s_px[threadIdx.x];
-      else if (gx < C.width && gy < C.height)
-        out[(size_t)gx + (size_t)gy * C.width] = s_px[threadIdx.x];
-    }
-    if (T.rgb) {
+  const uint32_t tile = k * T.world + T.rank;
+  const uint32_t tx = tile % T.tiles_x, ty = tile / T.tiles_x;
+  const uint32_t rx = threadIdx.x & 31u, ry = threadIdx.x >> 5;
+  const uint32_t gx = tx * 32u + rx, gy = ty * 8u + ry;
+  if (T.rgba8) {
+    uint32_t* out = reinterpret_cast<uint32_t*>(T.rgba8);
+    if (T.compact)
+      out[(size_t)k * 256u + threadIdx.x] = s_px[threadIdx.x];
+    else if (gx < C.width && gy < C.height)
+      out[(size_t)gx + (size_t)gy * C.width] = s_px[threadIdx.x];
+  }
+  if (T.rgb) {
 #pragma unroll
-      for (uint32_t pass = 0; pass < 3; ++pass) {
-        const uint32_t e = threadIdx.x + pass * 256u;
-        const uint32_t row = e / 96u, col = e % 96u;
-        if (T.compact) {
-          T.rgb[(size_t)k * 768u + e] = s_rgb[e];
-        } else {
-          const uint32_t fx = tx * 32u + col / 3u, fy = ty * 8u + row;
-          if (fx < C.width && fy < C.height) T.rgb[((size_t)fx + (size_t)fy * C.width) * 3u + col % 3u] = s_rgb[e];
-        }
+    for (uint32_t pass = 0; pass < 3; ++pass) {
+      const uint32_t e = threadIdx.x + pass * 256u;
+      const uint32_t row = e / 96u, col = e % 96u;
+      if (T.compact) {
+        T.rgb[(size_t)k * 768u + e] = s_rgb[e];
+      } else {
+        const uint32_t fx = tx * 32u + col / 3u, fy = ty * 8u + row;
+        if (fx < C.width && fy < C.height) T.rgb[((size_t)fx + (size_t)fy * C.width) * 3u + col % 3u] = s_rgb[e];
       }
     }
   }
+}
+
+// Kernel 3: shading and store from the hit records of the ray kernel(s).
+__global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, RenderTarget T, OpaqueBuffers B,
+                                                      DevCounters* counters) {
+  __shared__ float s_rgb[768];
+  __shared__ uint32_t s_px[256];
+  const uint32_t k = blockIdx.x;
+  const PixelRef px = pixel_ref(T, C, k);
+  V3 color = {0, 0, 0};
+  unsigned n_shadow = 0;
+  if (px.valid) {
+    color = ld3(S.ambient);  // a miss, or trace_inner at depth >= MAX_DEPTH, returns ambient_color
+    const uint32_t obj = B.hit_obj[px.local];
+    if (obj != 0xffffffffu) {
+      const uint8_t sh = B.shadow[px.local];
+      n_shadow = sh & 0x7fu;
+      color = shade_hit(S, C, px, obj, B.hit_t[px.local], (sh & 0x80u) != 0);
+    }
+  }
+  store_tile(C, T, k, color, s_rgb, s_px);
   n_shadow = wave_sum(n_shadow);
-  if (lane == 0) atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)n_shadow);
+  if ((threadIdx.x & 63u) == 0) atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)n_shadow);
+}
+
+// All three steps in one kernel (every light has w = 0): no hit records cross HBM.
+template <int KW>
+__global__ void __launch_bounds__(kBlock, 4) render_uniform_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
+                                                                  const float4* __restrict__ prim_ball,
+                                                                  const float4* __restrict__ prim_cluster, RenderTarget T,
+                                                                  DevCounters* counters) {
+  __shared__ float s_rgb[768];
+  __shared__ uint32_t s_px[256];
+  const uint32_t k = T.n_local_tiles - 1u - blockIdx.x;
+  const PixelRef px = pixel_ref(T, C, k);
+  Closest best;
+  unsigned n_exact = 0;
+  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, n_exact);
+  const uint32_t obj = px.valid ? best.obj : 0xffffffffu;
+  const bool hit = obj != 0xffffffffu;
+  V3 p = {0, 0, 0};
+  if (hit) p = over_point(S, C, px, obj, best.t);
+  unsigned rays = 0;
+  const bool in_shadow = shadow_phase_uniform<KW>(S, hit, p, rays, n_exact);
+  V3 color = {0, 0, 0};
+  if (px.valid) color = hit ? shade_hit(S, C, px, launder(obj), best.t, in_shadow) : ld3(S.ambient);
+  store_tile(C, T, k, color, s_rgb, s_px);
+  const unsigned n_primary = wave_sum(px.valid ? 1u : 0u);
+  rays = wave_sum(rays);
+  n_exact = wave_sum(n_exact);
+  if ((threadIdx.x & 63u) == 0) {
+    atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)n_primary);
+    atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)rays);
+    atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -520,11 +564,13 @@ hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCame
   if (T.n_local_tiles == 0) return after_rays ? hipEventRecord(after_rays, st) : hipSuccess;
   const dim3 tiles(T.n_local_tiles), block(kBlock);
   if (S.max_depth > 0) {
-    if (S.lights_uniform) {
-      if (S.k_width == 4)
-        hipLaunchKernelGGL((trace_uniform_kernel<4>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);
-      else
-        hipLaunchKernelGGL((trace_uniform_kernel<8>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);
+    if (S.lights_uniform && S.k_width == 4) {
+      // up to 4 lights: everything in one kernel (128 VGPRs hold it without spills)
+      hipLaunchKernelGGL((render_uniform_kernel<4>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, counters);
+      return after_rays ? hipEventRecord(after_rays, st) : hipGetLastError();
+    } else if (S.lights_uniform) {
+      // 5 to 64 lights in batches of 8: the wider filter state does not leave room for the shading code
+      hipLaunchKernelGGL((trace_uniform_kernel<8>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);
     } else {
       hipLaunchKernelGGL(primary_kernel, tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);
       switch (light_batch_for(S.n_lights)) {

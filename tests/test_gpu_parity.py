@@ -407,3 +407,10 @@ def test_random_rays_in_a_large_scene(rtk, dev, oracle):
     err = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
     assert (err.max(axis=1) > 1e-9).sum() <= 2, f"max {err.max():.3e}"
     h.release()
+
+
+def test_fifty_thousand_spheres(rtk, dev, oracle):
+    """782 clusters: several blocks of 64 clusters per wavefront-level sweep."""
+    scene = rtk.synthetic.make_scene(50000, True, 4, 555)
+    camera = rtk.synthetic.make_camera(50000, 96, 54)
+    check_against_oracle(dev, oracle, scene, camera, "50,000 spheres")

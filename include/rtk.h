@@ -200,6 +200,15 @@ int rtk_untile(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t world
                uint64_t slot_pixels, const float* d_rgb_f32_compact, float* d_rgb_f32_frame,
                const uint8_t* d_rgba8_compact, uint8_t* d_rgba8_frame, void* hip_stream);
 
+/* The same with an explicit distance in bytes between consecutive ranks' buffers, for
+ * callers that gather FP32 and RGBA8 tiles of a rank in ONE message (per rank: its FP32
+ * tiles, then its RGBA8 tiles; both strides are then the message size).  Strides must be
+ * multiples of 4. */
+int rtk_untile_strided(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t world,
+                       uint64_t rgb_rank_stride_bytes, uint64_t rgba8_rank_stride_bytes,
+                       const float* d_rgb_f32_compact, float* d_rgb_f32_frame,
+                       const uint8_t* d_rgba8_compact, uint8_t* d_rgba8_frame, void* hip_stream);
+
 /* Waits for the stream of the last render and returns its ray counts and kernel time. */
 int rtk_get_stats(rtk_context* ctx, rtk_stats* stats);
 

@@ -130,6 +130,11 @@ SYMBOLS = {
         [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_void_p],
     ),
+    "rtk_untile_strided": (
+        C.c_int,
+        [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_void_p, C.c_void_p],
+    ),
     "rtk_get_stats": (C.c_int, [C.c_void_p, C.POINTER(rtk_stats)]),
     "rtk_get_timing_history": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rtk_last_error": (C.c_char_p, []),

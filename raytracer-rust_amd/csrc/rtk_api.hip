@@ -780,20 +780,37 @@ int rtk_trace_rays(rtk_context* ctx, rtk_scene_handle* scene, const double* orig
   return RTK_OK;
 }
 
+static int untile_checked(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t world, uint64_t rgb_stride_bytes,
+                          uint64_t rgba8_stride_bytes, const float* d_rgb_f32_compact, float* d_rgb_f32_frame,
+                          const uint8_t* d_rgba8_compact, uint8_t* d_rgba8_frame, void* hip_stream, const char* who) {
+  if (!ctx || width == 0 || height == 0 || world == 0) return fail(RTK_ERR_INVALID, std::string(who) + ": bad argument");
+  if ((d_rgb_f32_compact == nullptr) != (d_rgb_f32_frame == nullptr) || (d_rgba8_compact == nullptr) != (d_rgba8_frame == nullptr))
+    return fail(RTK_ERR_INVALID, std::string(who) + ": compact and frame pointers must come in pairs");
+  if (rgb_stride_bytes % 4u != 0 || rgba8_stride_bytes % 4u != 0)
+    return fail(RTK_ERR_INVALID, std::string(who) + ": rank strides must be multiples of 4 bytes");
+  const uint64_t largest = rtk_compact_pixels(width, height, 0, world);  // rank 0 owns the most tiles
+  if ((d_rgb_f32_compact && world > 1 && rgb_stride_bytes < largest * 12u) ||
+      (d_rgba8_compact && world > 1 && rgba8_stride_bytes < largest * 4u))
+    return fail(RTK_ERR_INVALID, std::string(who) + ": rank stride smaller than a rank's compact buffer");
+  RTK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  RTK_HIP(rtk::launch_untile(st, width, height, world, rgb_stride_bytes / 4u, rgba8_stride_bytes / 4u, d_rgb_f32_compact,
+                             d_rgb_f32_frame, d_rgba8_compact, d_rgba8_frame));
+  return RTK_OK;
+}
+
 int rtk_untile(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t world, uint64_t slot_pixels,
                const float* d_rgb_f32_compact, float* d_rgb_f32_frame, const uint8_t* d_rgba8_compact,
                uint8_t* d_rgba8_frame, void* hip_stream) {
-  if (!ctx || width == 0 || height == 0 || world == 0) return fail(RTK_ERR_INVALID, "rtk_untile: bad argument");
-  if ((d_rgb_f32_compact == nullptr) != (d_rgb_f32_frame == nullptr) || (d_rgba8_compact == nullptr) != (d_rgba8_frame == nullptr))
-    return fail(RTK_ERR_INVALID, "rtk_untile: compact and frame pointers must come in pairs");
-  for (uint32_t r = 0; r < world; ++r)
-    if (rtk_compact_pixels(width, height, r, world) > slot_pixels)
-      return fail(RTK_ERR_INVALID, "rtk_untile: slot_pixels smaller than a rank's compact buffer");
-  RTK_HIP(hipSetDevice(ctx->device));
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-  RTK_HIP(rtk::launch_untile(st, width, height, world, slot_pixels, d_rgb_f32_compact, d_rgb_f32_frame, d_rgba8_compact,
-                             d_rgba8_frame));
-  return RTK_OK;
+  return untile_checked(ctx, width, height, world, slot_pixels * 12u, slot_pixels * 4u, d_rgb_f32_compact, d_rgb_f32_frame,
+                        d_rgba8_compact, d_rgba8_frame, hip_stream, "rtk_untile");
+}
+
+int rtk_untile_strided(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t world, uint64_t rgb_rank_stride_bytes,
+                       uint64_t rgba8_rank_stride_bytes, const float* d_rgb_f32_compact, float* d_rgb_f32_frame,
+                       const uint8_t* d_rgba8_compact, uint8_t* d_rgba8_frame, void* hip_stream) {
+  return untile_checked(ctx, width, height, world, rgb_rank_stride_bytes, rgba8_rank_stride_bytes, d_rgb_f32_compact,
+                        d_rgb_f32_frame, d_rgba8_compact, d_rgba8_frame, hip_stream, "rtk_untile_strided");
 }
 
 }  // extern "C"

@@ -29,9 +29,10 @@ hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCame
 hipError_t launch_trace_rays(hipStream_t st, const DevScene& S, const double* origins, const double* directions, uint64_t n,
                              double* colors, DevCounters* counters);
 
-// Compact per-rank tile buffers -> row-major frame.
-hipError_t launch_untile(hipStream_t st, uint32_t width, uint32_t height, uint32_t world, uint64_t slot_pixels,
-                         const float* rgb_c, float* rgb_f, const uint8_t* px_c, uint8_t* px_f);
+// Compact per-rank tile buffers -> row-major frame.  Rank r's FP32 tiles start
+// r * rgb_stride_floats floats into rgb_c, its RGBA8 tiles r * px_stride_pixels pixels into px_c.
+hipError_t launch_untile(hipStream_t st, uint32_t width, uint32_t height, uint32_t world, uint64_t rgb_stride_floats,
+                         uint64_t px_stride_pixels, const float* rgb_c, float* rgb_f, const uint8_t* px_c, uint8_t* px_f);
 
 }  // namespace rtk
 #endif

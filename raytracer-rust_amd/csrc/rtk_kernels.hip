@@ -308,26 +308,28 @@ __global__ void __launch_bounds__(kBlock) prep_primary_kernel(DevScene S, DevCam
   }
 }
 
-// Rebuilds row-major frames from `world` compact tile buffers laid end to end.
+// Rebuilds row-major frames from `world` compact tile buffers: rank r's FP32 tiles start
+// rgb_stride floats after rank r-1's, its RGBA8 tiles px_stride pixels after rank r-1's.
 __global__ void __launch_bounds__(kBlock) untile_kernel(uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles,
-                                                        uint32_t world, uint64_t slot_pixels, const float* __restrict__ rgb_c,
-                                                        float* __restrict__ rgb_f, const uint32_t* __restrict__ px_c,
-                                                        uint32_t* __restrict__ px_f) {
+                                                        uint32_t world, uint64_t rgb_stride, uint64_t px_stride,
+                                                        const float* __restrict__ rgb_c, float* __restrict__ rgb_f,
+                                                        const uint32_t* __restrict__ px_c, uint32_t* __restrict__ px_f) {
   const uint32_t tile = blockIdx.x;
   if (tile >= n_tiles) return;
   const uint32_t rank = tile % world, k = tile / world;
   const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-  const size_t src = (size_t)rank * slot_pixels + (size_t)k * 256u;
   const uint32_t rx = threadIdx.x & 31u, ry = threadIdx.x >> 5;
   const uint32_t gx = tx * 32u + rx, gy = ty * 8u + ry;
-  if (px_c && gx < width && gy < height) px_f[(size_t)gx + (size_t)gy * width] = px_c[src + threadIdx.x];
+  if (px_c && gx < width && gy < height)
+    px_f[(size_t)gx + (size_t)gy * width] = px_c[(size_t)rank * px_stride + (size_t)k * 256u + threadIdx.x];
   if (rgb_c) {
+    const float* src = rgb_c + (size_t)rank * rgb_stride + (size_t)k * 768u;
 #pragma unroll
     for (uint32_t pass = 0; pass < 3; ++pass) {
       const uint32_t e = threadIdx.x + pass * 256u;
       const uint32_t row = e / 96u, col = e % 96u;
       const uint32_t px = tx * 32u + col / 3u, py = ty * 8u + row;
-      if (px < width && py < height) rgb_f[((size_t)px + (size_t)py * width) * 3u + col % 3u] = rgb_c[src * 3u + e];
+      if (px < width && py < height) rgb_f[((size_t)px + (size_t)py * width) * 3u + col % 3u] = src[e];
     }
   }
 }
@@ -397,13 +399,14 @@ hipError_t launch_trace_rays(hipStream_t st, const DevScene& S, const double* or
   if (S.n_spheres >= kWideScene) return launch_trace_rays_lb<true>(lb, grid, st, S, origins, directions, n, colors, counters);
   return launch_trace_rays_lb<false>(lb, grid, st, S, origins, directions, n, colors, counters);
 }
-hipError_t launch_untile(hipStream_t st, uint32_t width, uint32_t height, uint32_t world, uint64_t slot_pixels,
-                         const float* rgb_c, float* rgb_f, const uint8_t* px_c, uint8_t* px_f) {
+hipError_t launch_untile(hipStream_t st, uint32_t width, uint32_t height, uint32_t world, uint64_t rgb_stride_floats,
+                         uint64_t px_stride_pixels, const float* rgb_c, float* rgb_f, const uint8_t* px_c, uint8_t* px_f) {
   const uint32_t tiles_x = (width + 31u) / 32u, tiles_y = (height + 7u) / 8u;
   const uint32_t n_tiles = tiles_x * tiles_y;
   if (n_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(untile_kernel, dim3(n_tiles), dim3(kBlock), 0, st, width, height, tiles_x, n_tiles, world, slot_pixels,
-                     rgb_c, rgb_f, reinterpret_cast<const uint32_t*>(px_c), reinterpret_cast<uint32_t*>(px_f));
+  hipLaunchKernelGGL(untile_kernel, dim3(n_tiles), dim3(kBlock), 0, st, width, height, tiles_x, n_tiles, world,
+                     rgb_stride_floats, px_stride_pixels, rgb_c, rgb_f, reinterpret_cast<const uint32_t*>(px_c),
+                     reinterpret_cast<uint32_t*>(px_f));
   return hipGetLastError();
 }
 

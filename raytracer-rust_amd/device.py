@@ -168,8 +168,10 @@ class Device:
         return out
 
     def untile(self, width, height, world, slot_pixels, rgb_compact=None, rgba8_compact=None, out_rgb=None,
-               out_rgba8=None):
-        """Compact per-rank tile buffers laid end to end -> row-major frames (device tensors)."""
+               out_rgba8=None, rank_stride_bytes=None):
+        """Compact per-rank tile buffers -> row-major frames (device tensors).  By default the ranks'
+        buffers lie end to end, `slot_pixels` each; with `rank_stride_bytes` every rank's FP32 and
+        RGBA8 buffers start that many bytes after the previous rank's (one gathered message per rank)."""
         torch = self.torch
         rgb = rgba = None
         if rgb_compact is not None:
@@ -177,13 +179,15 @@ class Device:
         if rgba8_compact is not None:
             rgba = out_rgba8 if out_rgba8 is not None else torch.empty((height, width, 4), dtype=torch.uint8, device=self.tdev)
         stream = torch.cuda.current_stream(self.tdev).cuda_stream
-        _check(library().rtk_untile(
-            self.ctx, width, height, world, slot_pixels,
-            C.c_void_p(rgb_compact.data_ptr()) if rgb_compact is not None else None,
-            C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
-            C.c_void_p(rgba8_compact.data_ptr()) if rgba8_compact is not None else None,
-            C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
-            C.c_void_p(stream)))
+        ptrs = (C.c_void_p(rgb_compact.data_ptr()) if rgb_compact is not None else None,
+                C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
+                C.c_void_p(rgba8_compact.data_ptr()) if rgba8_compact is not None else None,
+                C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
+                C.c_void_p(stream))
+        if rank_stride_bytes is None:
+            _check(library().rtk_untile(self.ctx, width, height, world, slot_pixels, *ptrs))
+        else:
+            _check(library().rtk_untile_strided(self.ctx, width, height, world, rank_stride_bytes, rank_stride_bytes, *ptrs))
         return rgb, rgba
 
 

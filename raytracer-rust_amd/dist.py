@@ -3,9 +3,9 @@
 Pixels are independent (the reference's loop has no cross-iteration state,
 src/scene/cameras.rs:75-82), so the frame shards with no data-path collective: rank r of
 `world` renders the 32x8 tiles t with t % world == r (round-robin keeps sky and ground
-tiles evenly mixed).  The only exchange is one gather of the compact tile buffers to rank 0
-per frame -- over xGMI through RCCL when the process group's backend is "nccl" -- followed
-by one de-interleave kernel on rank 0.
+tiles evenly mixed).  The only exchange is ONE gather per frame of each rank's compact tile
+buffers (FP32 and RGBA8 in one message) to rank 0 -- over xGMI through RCCL when the process
+group's backend is "nccl" -- followed by one de-interleave kernel on rank 0.
 
 One process per GPU; the process group is the caller's (`torch.distributed`).
 The render and the de-interleave step are injectable so that the partition and gather
@@ -61,7 +61,12 @@ class DistributedRenderer:
         tensors [slot, 3] float32 and [slot, 4] uint8; either may be None) -- compact
         tile-major layout when world > 1, the row-major frame itself (first W*H pixels)
         when world == 1, exactly as rtk_render_device lays them out.
-    untile(gathered_rgb, gathered_rgba8): rank-0 only, world > 1; [world*slot, c] -> frames.
+    untile(message, rgb_view, rgba8_view, stride_bytes): rank-0 only, world > 1; `message` is the
+        gathered [world, stride_bytes] uint8 tensor, the views are rank 0's parts of it
+        (None for an output that was not asked for) -> (rgb frame, rgba8 frame).
+
+    A rank's FP32 and RGBA8 tiles travel in ONE message (FP32 part first), so a frame costs one
+    gather whatever outputs are wanted.
     """
 
     def __init__(self, width, height, group=None, want_rgb=True, want_rgba8=True, tensor_device=None,
@@ -79,23 +84,19 @@ class DistributedRenderer:
         self.render_compact, self.untile = render_compact, untile
         dev = tensor_device if tensor_device is not None else torch.device("cpu")
         # fixed buffers: nothing is allocated per frame
-        self.rgb = torch.zeros((self.slot, 3), dtype=torch.float32, device=dev) if want_rgb else None
-        self.rgba8 = torch.zeros((self.slot, 4), dtype=torch.uint8, device=dev) if want_rgba8 else None
-        self.g_rgb = self.g_rgba8 = None
+        self.rgb_bytes = self.slot * 12 if want_rgb else 0
+        self.message_bytes = self.rgb_bytes + (self.slot * 4 if want_rgba8 else 0)
+        self.message = torch.zeros(self.message_bytes, dtype=torch.uint8, device=dev)
+        self.rgb, self.rgba8 = self._views(self.message)
+        self.gathered = None
         if self.rank == 0 and self.world > 1:
-            if want_rgb:
-                self.g_rgb = torch.zeros((self.world * self.slot, 3), dtype=torch.float32, device=dev)
-            if want_rgba8:
-                self.g_rgba8 = torch.zeros((self.world * self.slot, 4), dtype=torch.uint8, device=dev)
+            self.gathered = torch.zeros((self.world, self.message_bytes), dtype=torch.uint8, device=dev)
 
-    def _gather(self, local, gathered):
-        if local is None:
-            return
-        if self.rank == 0:
-            chunks = list(gathered.view(self.world, *local.shape).unbind(0))
-            self.dist.gather(local, gather_list=chunks, dst=0, group=self.group)
-        else:
-            self.dist.gather(local, gather_list=None, dst=0, group=self.group)
+    def _views(self, message):
+        """([slot, 3] float32, [slot, 4] uint8) views of one rank's message."""
+        rgb = message[: self.rgb_bytes].view(self.torch.float32).view(self.slot, 3) if self.want_rgb else None
+        rgba8 = message[self.rgb_bytes:].view(self.slot, 4) if self.want_rgba8 else None
+        return rgb, rgba8
 
     def frame(self):
         """One frame.  Returns (rgb, rgba8) frames on rank 0, (None, None) elsewhere."""
@@ -105,11 +106,13 @@ class DistributedRenderer:
             rgb = self.rgb[:n].view(self.height, self.width, 3) if self.rgb is not None else None
             rgba8 = self.rgba8[:n].view(self.height, self.width, 4) if self.rgba8 is not None else None
             return rgb, rgba8
-        self._gather(self.rgb, self.g_rgb)
-        self._gather(self.rgba8, self.g_rgba8)
-        if self.rank != 0:
+        if self.rank == 0:
+            self.dist.gather(self.message, gather_list=list(self.gathered.unbind(0)), dst=0, group=self.group)
+        else:
+            self.dist.gather(self.message, gather_list=None, dst=0, group=self.group)
             return None, None
-        return self.untile(self.g_rgb, self.g_rgba8)
+        rgb0, rgba0 = self._views(self.gathered[0])
+        return self.untile(self.gathered, rgb0, rgba0, self.message_bytes)
 
 
 def gpu_renderer(device, handle, camera, group=None, want_rgb=True, want_rgba8=True):
@@ -122,17 +125,15 @@ def gpu_renderer(device, handle, camera, group=None, want_rgb=True, want_rgba8=T
 
     frames = {}
 
-    def untile(g_rgb, g_rgba8):
-        import torch.distributed as dist
-
-        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    def untile(message, rgb0, rgba0, stride_bytes):
+        world = message.shape[0]
         torch = device.torch
-        if g_rgb is not None and "rgb" not in frames:
+        if rgb0 is not None and "rgb" not in frames:
             frames["rgb"] = torch.empty((h, w, 3), dtype=torch.float32, device=device.tdev)
-        if g_rgba8 is not None and "rgba8" not in frames:
+        if rgba0 is not None and "rgba8" not in frames:
             frames["rgba8"] = torch.empty((h, w, 4), dtype=torch.uint8, device=device.tdev)
-        return device.untile(w, h, world, slot_pixels(w, h, world), g_rgb, g_rgba8, frames.get("rgb"),
-                             frames.get("rgba8"))
+        return device.untile(w, h, world, slot_pixels(w, h, world), rgb0, rgba0, frames.get("rgb"), frames.get("rgba8"),
+                             rank_stride_bytes=stride_bytes)
 
     return DistributedRenderer(w, h, group, want_rgb, want_rgba8, device.tdev, render_compact, untile)
 

@@ -55,9 +55,13 @@ def _worker(rank, world, port, w, h, out_path):
             k += 1
         assert k == rdist.tiles_for_rank(w, h, r, wd)
 
-    def untile(g_rgb, g_rgba8):
+    def untile(message, rgb0, rgba0, stride_bytes):
+        # one message per rank: its FP32 tiles, then its RGBA8 tiles
         slot = rdist.slot_pixels(w, h, world)
-        return (rdist.untile_host(w, h, world, slot, g_rgb.numpy(), 3), rdist.untile_host(w, h, world, slot, g_rgba8.numpy(), 4))
+        assert message.shape == (world, stride_bytes) and stride_bytes == slot * 16
+        g_rgb = np.concatenate([message[r, : slot * 12].numpy().view(np.float32).reshape(slot, 3) for r in range(world)])
+        g_rgba8 = np.concatenate([message[r, slot * 12:].numpy().reshape(slot, 4) for r in range(world)])
+        return (rdist.untile_host(w, h, world, slot, g_rgb, 3), rdist.untile_host(w, h, world, slot, g_rgba8, 4))
 
     renderer = rdist.DistributedRenderer(w, h, render_compact=render_compact, untile=untile)
     assert renderer.world == world and renderer.rank == rank

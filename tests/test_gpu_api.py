@@ -90,6 +90,37 @@ def test_tiled_render_is_bit_identical_to_single_rank(rtk, dev, world, name, w, 
     assert np.array_equal(dist.untile_host(w, h, world, slot, g_rgba.cpu().numpy(), 4), rgba1.cpu().numpy())
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_strided_untile_of_one_message_per_rank(rtk, dev, world):
+    """The layout the multi-GPU renderer gathers: per rank one message = FP32 tiles then RGBA8 tiles."""
+    import torch
+
+    dist = importlib.import_module("raytracer-rust_amd.dist")
+    w, h = 250, 131
+    scene, camera = rtk.synthetic.config("C2", w, h)
+    handle = dev.upload(scene)
+    rgb1, rgba1 = dev.render_device(handle, camera)
+    slot = dist.slot_pixels(w, h, world)
+    message = torch.zeros((world, slot * 16), dtype=torch.uint8, device=dev.tdev)
+    for rank in range(world):
+        n = dist.tiles_for_rank(w, h, rank, world) * 256
+        rgb = message[rank, : slot * 12].view(torch.float32).view(slot, 3)
+        rgba = message[rank, slot * 12:].view(slot, 4)
+        dev.render_device(handle, camera, rank=rank, world=world, out_rgb=rgb[:n], out_rgba8=rgba[:n])
+    rgb0 = message[0, : slot * 12].view(torch.float32).view(slot, 3)
+    rgba0 = message[0, slot * 12:].view(slot, 4)
+    f_rgb, f_rgba = dev.untile(w, h, world, slot, rgb0, rgba0, rank_stride_bytes=slot * 16)
+    torch.cuda.synchronize()
+    assert torch.equal(f_rgb, rgb1) and torch.equal(f_rgba, rgba1)
+    # only one of the outputs
+    f_rgb, f_rgba = dev.untile(w, h, world, slot, None, rgba0, rank_stride_bytes=slot * 16)
+    torch.cuda.synchronize()
+    assert f_rgb is None and torch.equal(f_rgba, rgba1)
+    device_mod = importlib.import_module("raytracer-rust_amd.device")
+    with pytest.raises(device_mod.RtkError):
+        dev.untile(w, h, world, slot, rgb0, rgba0, rank_stride_bytes=slot * 4 - 4)  # smaller than a rank's buffer
+
+
 def test_distributed_renderer_single_process(rtk, dev):
     import torch
 

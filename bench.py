@@ -114,7 +114,8 @@ def main():
         if world > 1:
             tdist.barrier()
 
-    # Steps are queued back to back; nothing waits on a frame inside the timed region.  The
+    # Steps are queued back to back (with more than one GPU two frames are in flight: the gather of
+    # one overlaps the render of the next); nothing waits on a frame inside the timed region.  The
     # library keeps HIP-event times of its last 64 launches (events on the launch stream),
     # read after the region; the ray counters are those of the last frame (every frame of a
     # fixed scene traces the same rays).
@@ -122,8 +123,8 @@ def main():
         renderer.frame()
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        renderer.frame()
+    for _ in renderer.stream(args.steps):  # every frame is complete on rank 0 when the loop ends
+        pass
     torch.cuda.synchronize()
     if world > 1:
         tdist.barrier()

@@ -67,10 +67,19 @@ class DistributedRenderer:
 
     A rank's FP32 and RGBA8 tiles travel in ONE message (FP32 part first), so a frame costs one
     gather whatever outputs are wanted.
+
+    `frame()` renders, gathers and de-interleaves one frame.  For a stream of frames use
+    `submit()` / `collect()`: up to two frames may be in flight, so the gather of frame k (on the
+    communication stream of the process group) overlaps rank 0's de-interleave of frame k-1 and
+    every rank's render of frame k+1.  Two message buffers alternate; nothing is allocated per frame.
     """
 
+    DEPTH = 2
+
     def __init__(self, width, height, group=None, want_rgb=True, want_rgba8=True, tensor_device=None,
-                 render_compact=None, untile=None):
+                 render_compact=None, untile=None, always_gather=False):
+        import collections
+
         import torch
         import torch.distributed as dist
 
@@ -83,14 +92,20 @@ class DistributedRenderer:
         self.want_rgb, self.want_rgba8 = want_rgb, want_rgba8
         self.render_compact, self.untile = render_compact, untile
         dev = tensor_device if tensor_device is not None else torch.device("cpu")
-        # fixed buffers: nothing is allocated per frame
         self.rgb_bytes = self.slot * 12 if want_rgb else 0
         self.message_bytes = self.rgb_bytes + (self.slot * 4 if want_rgba8 else 0)
-        self.message = torch.zeros(self.message_bytes, dtype=torch.uint8, device=dev)
-        self.rgb, self.rgba8 = self._views(self.message)
+        self.messages = [torch.zeros(self.message_bytes, dtype=torch.uint8, device=dev) for _ in range(self.DEPTH)]
         self.gathered = None
         if self.rank == 0 and self.world > 1:
-            self.gathered = torch.zeros((self.world, self.message_bytes), dtype=torch.uint8, device=dev)
+            self.gathered = [torch.zeros((self.world, self.message_bytes), dtype=torch.uint8, device=dev)
+                             for _ in range(self.DEPTH)]
+        # always_gather: a single rank still sends its frame through the process group (to itself),
+        # which exercises the collective path on one GPU
+        self.always_gather = bool(always_gather) and dist.is_initialized()
+        if self.always_gather and self.gathered is None:
+            self.gathered = [torch.zeros((1, self.message_bytes), dtype=torch.uint8, device=dev) for _ in range(self.DEPTH)]
+        self.in_flight = collections.deque()  # (buffer index, gather handle or None), oldest first
+        self.submitted = 0
 
     def _views(self, message):
         """([slot, 3] float32, [slot, 4] uint8) views of one rank's message."""
@@ -98,24 +113,53 @@ class DistributedRenderer:
         rgba8 = message[self.rgb_bytes:].view(self.slot, 4) if self.want_rgba8 else None
         return rgb, rgba8
 
-    def frame(self):
-        """One frame.  Returns (rgb, rgba8) frames on rank 0, (None, None) elsewhere."""
-        self.render_compact(self.rank, self.world, self.rgb, self.rgba8)
+    def submit(self):
+        """Starts the next frame: this rank's tiles, then (world > 1) the gather, without waiting."""
+        if len(self.in_flight) >= self.DEPTH:
+            raise RuntimeError("DistributedRenderer: collect() a frame before submitting a third")
+        i = self.submitted % self.DEPTH
+        self.submitted += 1
+        rgb, rgba8 = self._views(self.messages[i])
+        self.render_compact(self.rank, self.world, rgb, rgba8)
+        work = None
+        if self.world > 1 or self.always_gather:
+            targets = list(self.gathered[i].unbind(0)) if self.rank == 0 else None
+            work = self.dist.gather(self.messages[i], gather_list=targets, dst=0, group=self.group, async_op=True)
+        self.in_flight.append((i, work))
+
+    def collect(self):
+        """Finishes the oldest frame in flight.  Returns (rgb, rgba8) frames on rank 0, (None, None) elsewhere."""
+        i, work = self.in_flight.popleft()
         if self.world == 1:
+            if work is not None:
+                work.wait()
             n = self.width * self.height
-            rgb = self.rgb[:n].view(self.height, self.width, 3) if self.rgb is not None else None
-            rgba8 = self.rgba8[:n].view(self.height, self.width, 4) if self.rgba8 is not None else None
+            rgb, rgba8 = self._views(self.gathered[i][0] if work is not None else self.messages[i])
+            rgb = rgb[:n].view(self.height, self.width, 3) if rgb is not None else None
+            rgba8 = rgba8[:n].view(self.height, self.width, 4) if rgba8 is not None else None
             return rgb, rgba8
-        if self.rank == 0:
-            self.dist.gather(self.message, gather_list=list(self.gathered.unbind(0)), dst=0, group=self.group)
-        else:
-            self.dist.gather(self.message, gather_list=None, dst=0, group=self.group)
+        work.wait()  # device tensors: the current stream waits for the gather; host tensors: the host does
+        if self.rank != 0:
             return None, None
-        rgb0, rgba0 = self._views(self.gathered[0])
-        return self.untile(self.gathered, rgb0, rgba0, self.message_bytes)
+        rgb0, rgba0 = self._views(self.gathered[i][0])
+        return self.untile(self.gathered[i], rgb0, rgba0, self.message_bytes)
+
+    def frame(self):
+        """One frame, start to finish."""
+        self.submit()
+        return self.collect()
+
+    def stream(self, n):
+        """n frames with two in flight; yields each frame's (rgb, rgba8) in order."""
+        for k in range(n):
+            self.submit()
+            if k > 0:
+                yield self.collect()
+        if n > 0:
+            yield self.collect()
 
 
-def gpu_renderer(device, handle, camera, group=None, want_rgb=True, want_rgba8=True):
+def gpu_renderer(device, handle, camera, group=None, want_rgb=True, want_rgba8=True, always_gather=False):
     """DistributedRenderer wired to the HIP path: compact tile render + device untile."""
     cam = camera.to_abi() if hasattr(camera, "to_abi") else camera
     w, h = cam.width, cam.height
@@ -135,7 +179,7 @@ def gpu_renderer(device, handle, camera, group=None, want_rgb=True, want_rgba8=T
         return device.untile(w, h, world, slot_pixels(w, h, world), rgb0, rgba0, frames.get("rgb"), frames.get("rgba8"),
                              rank_stride_bytes=stride_bytes)
 
-    return DistributedRenderer(w, h, group, want_rgb, want_rgba8, device.tdev, render_compact, untile)
+    return DistributedRenderer(w, h, group, want_rgb, want_rgba8, device.tdev, render_compact, untile, always_gather)
 
 
 def _render_compact(device, handle, cam, rank, world, out_rgb, out_rgba8):

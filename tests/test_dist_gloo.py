@@ -70,6 +70,24 @@ def _worker(rank, world, port, w, h, out_path):
         np.savez(out_path, rgb=rgb, rgba=rgba)
     else:
         assert rgb is None and rgba is None
+    # a stream of frames with two in flight delivers the same frame every time, in order
+    n = 0
+    for f_rgb, f_rgba in renderer.stream(3):
+        n += 1
+        if rank == 0:
+            assert np.array_equal(f_rgb, rgb) and np.array_equal(f_rgba, rgba)
+        else:
+            assert f_rgb is None and f_rgba is None
+    assert n == 3 and not renderer.in_flight
+    renderer.submit()
+    renderer.submit()
+    try:
+        renderer.submit()
+        raise AssertionError("a third frame in flight was accepted")
+    except RuntimeError:
+        pass
+    renderer.collect()
+    renderer.collect()
     tdist.barrier()
     tdist.destroy_process_group()
 

@@ -1,6 +1,7 @@
 """Error behaviour and the tiled (multi-rank) entry points of the C ABI, on the device."""
 import ctypes as C
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -132,6 +133,12 @@ def test_distributed_renderer_single_process(rtk, dev):
     want_rgb, want_rgba = dev.render_device(handle, camera)
     torch.cuda.synchronize()
     assert torch.equal(rgb, want_rgb) and torch.equal(rgba, want_rgba)
+    frames = 0
+    for f_rgb, f_rgba in r.stream(5):  # two frames in flight, alternating buffers
+        torch.cuda.synchronize()
+        assert torch.equal(f_rgb, want_rgb) and torch.equal(f_rgba, want_rgba)
+        frames += 1
+    assert frames == 5
 
 
 def test_render_on_a_caller_stream(rtk, dev):
@@ -171,3 +178,49 @@ def test_timing_history_of_back_to_back_frames(rtk, dev):
     assert k[0] > 0.0 and k[0] == r[0]
     h.release()
     hg.release()
+
+
+_RCCL_SCRIPT = r"""
+import importlib, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as tdist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", sys.argv[2])
+torch.cuda.set_device(0)
+tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+rtk = importlib.import_module("raytracer-rust_amd")
+device = importlib.import_module("raytracer-rust_amd.device")
+rdist = importlib.import_module("raytracer-rust_amd.dist")
+dev = device.Device(0)
+scene, camera = rtk.synthetic.config("C3", 384, 216)
+handle = dev.upload(scene)
+want_rgb, want_rgba = dev.render_device(handle, camera)
+r = rdist.gpu_renderer(dev, handle, camera, always_gather=True)
+n = 0
+for rgb, rgba in r.stream(6):
+    torch.cuda.synchronize()
+    assert torch.equal(rgb, want_rgb) and torch.equal(rgba, want_rgba), "frame %d differs" % n
+    n += 1
+assert n == 6
+tdist.barrier()
+tdist.destroy_process_group()
+print("RCCL_PATH_OK")
+"""
+
+
+def test_frames_through_the_rccl_process_group(tmp_path):
+    """One rank, backend "nccl" (RCCL): every frame of a pipelined stream goes through an asynchronous
+    gather on the communication stream, exactly the calls the multi-GPU path makes."""
+    import socket
+    import subprocess
+    import sys
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "rccl_frames.py"
+    script.write_text(_RCCL_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, str(script), root, str(port)], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

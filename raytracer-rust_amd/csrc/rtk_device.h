@@ -1,5 +1,5 @@
 // rtk_device.h -- data layout shared by the host side (rtk_api.hip) and the kernels
-// (rtk_kernels.hip).  Everything here lives in HBM and is read-only during a render.
+// (rtk_kernels.hip, rtk_opaque.hip).  Everything here lives in HBM and is read-only during a render.
 #ifndef RTK_DEVICE_H
 #define RTK_DEVICE_H
 
@@ -9,11 +9,9 @@
 namespace rtk {
 
 constexpr int kBlock = 256;      // threads per workgroup = one 32x8 pixel tile (4 waves of 8x8)
-constexpr int kChunk = 1024;     // sphere filter records staged in LDS per pass (16 KiB)
 constexpr int kGroup = 8;        // records per wavefront early-out branch (one ray per lane)
 constexpr int kBundle = 64;      // records per wavefront-level test (one sphere per lane); arrays are padded to this
 constexpr int kMaxDepth = 8;     // == RTK_MAX_DEPTH_LIMIT
-constexpr int kMaxLightBatch = 8;
 
 constexpr float kEps32 = 5.9604645e-8f;  // 2^-24, unit round-off of FP32
 

@@ -1,25 +1,26 @@
-// rtk_kernels.hip -- gfx950 kernels of the ray-trace core.
+// rtk_kernels.hip -- the single-kernel path (scenes with reflective or transparent
+// materials, caller-supplied rays), the per-camera record kernel and the de-interleave
+// kernel of the multi-rank path.  Scenes with opaque materials only run rtk_opaque.hip.
 //
 // One thread traces one pixel (reference loop: src/scene/cameras.rs:72-85); one
 // 256-thread workgroup owns a 32x8 pixel tile, its four wavefronts own 8x8 sub-tiles so
-// that the 64 rays of a wavefront stay coherent.
+// that the 64 camera rays of a wavefront stay coherent.
 //
-// Every "ray" (one `Scene::intersect` call of the reference, src/scene.rs:156-169) is a
-// brute-force sweep over ALL objects:
+// Every "ray" is one `Scene::intersect` call of the reference (src/scene.rs:156-169): which
+// objects does it hit, and where.
 //   1. planes are few: each is intersected exactly in f64;
-//   2. spheres go through a conservative FP32 filter fed from LDS.  The filter answers
-//      "can the ray's line touch the sphere's bounding ball at all?" with enough slack to
-//      cover every rounding error, so it never rejects a real hit.  Eight records are
-//      tested per wavefront branch; only when some lane keeps a candidate does the
-//      wavefront leave the fast loop;
+//   2. spheres are walked cluster by cluster (rtk_sweeps.h): a conservative FP32 test per
+//      (ray, cluster ball), then per (ray, sphere) -- "can the ray's line touch the bounding
+//      ball at all?" with enough slack to cover every rounding error, so no real hit is
+//      ever rejected;
 //   3. kept candidates are re-evaluated in f64 with the reference's own formulas
 //      (object-space ray, unit sphere quadratic), so every decision -- closest hit,
 //      tie-break, shadow -- is taken on f64 values like the reference takes it.
 // Shading (LightingData, Phong, reflection, refraction, Schlick) is O(1) per ray and
 // runs in f64 in registers; the result is narrowed to FP32 / RGBA8 at the store.
 //
-// VALU-bound by design: no MFMA (nothing here is a dense contraction), HBM traffic is
-// the framebuffer store plus one pass over the 16-byte records per workgroup sweep.
+// No MFMA (nothing here is a dense contraction); HBM traffic is the framebuffer store; the
+// scene records stay in L2.
 
 #include "rtk_shading.h"
 #include "rtk_sweeps.h"
@@ -33,8 +34,8 @@ namespace rtk {
 // `Scene::trace` (src/scene.rs:136-296) for one ray per thread, evaluated iteratively:
 // child colours enter their parent linearly with scalar factors (reflectivity,
 // transparency, Schlick reflectance), so each node adds weight * surface to the pixel and
-// pushes its children with the product weight.  SECONDARY = false removes the stack for
-// scenes without reflective or transparent materials.
+// pushes its children with the product weight.  SECONDARY = false would remove the stack;
+// every kernel built from this file traces secondary rays.
 struct StackEntry {
   double ox, oy, oz, dx, dy, dz, weight;
   int depth;

@@ -121,13 +121,6 @@ __device__ __forceinline__ void closest_consider(Closest& c, double t, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------
-// LDS staging of one chunk of 16-byte filter records (all 256 threads take part).
-__device__ __forceinline__ void stage_chunk(float4* s_buf, const float4* __restrict__ src, uint32_t base, uint32_t count) {
-  __syncthreads();  // previous chunk fully consumed
-  for (uint32_t i = threadIdx.x; i < count; i += kBlock) s_buf[i] = src[base + i];
-  __syncthreads();
-}
-
 // Per-lane set-up of one filter ray.  For a light at L (w = L.w) seen from p the
 // reference's shadow ray has direction (L - p)/m with a w component (L.w - 1)/m that the
 // object's inverse transform turns into a per-object shift (src/scene.rs:208-225,

@@ -503,7 +503,7 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
     gd[4 * k + 3] = -inv;  // rho = (w - 1)/|G|
     light_filter[k] = make_float4((float)gd[4 * k], (float)gd[4 * k + 1], (float)gd[4 * k + 2], (float)gd[4 * k + 3]);
   }
-  const uint32_t k_width = scene->n_lights <= 4 ? 4u : 8u;
+  const uint32_t k_width = 4u;  // lights per table row and per sweep batch
   std::vector<float> k_table;
   std::vector<float4> sph_tab;
   if (lights_uniform && n_pad) {

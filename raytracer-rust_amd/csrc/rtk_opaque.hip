@@ -2,15 +2,14 @@
 // materials (every throughput configuration).  One pixel per lane, one 8x8 patch per
 // wavefront, one 32x8 tile per workgroup.
 //
-//   render_uniform_kernel<4>  every light has w = 0, at most 4 lights: camera ray, the
-//                    shadow rays of its hit towards all lights, shading and the store, in
-//                    one kernel; nothing but the framebuffer crosses HBM
-//   trace_uniform_kernel<8>   every light has w = 0, 5..64 lights in batches of 8: camera
-//                    and shadow rays; writes the hit (object, t), the reference's shadow
-//                    flag and its shadow-ray count (13 bytes per pixel) for shade_kernel
-//   primary_kernel + shadow_general_kernel   the same in two kernels when some light has w != 0
-//   shade_kernel     rebuilds LightingData, samples the texture, sums Phong over the
-//                    lights and stores FP32 RGB + RGBA8 (transposed through LDS)
+//   render_uniform_kernel  every light has w = 0 (what scene files give): camera ray, the
+//                    shadow rays of its hit towards all lights (batches of 4), shading and
+//                    the store, in one kernel; nothing but the framebuffer crosses HBM
+//   primary_kernel + shadow_general_kernel + shade_kernel   when some light has w != 0:
+//                    camera rays, shadow rays (per-ray cluster walk) and shading as three
+//                    kernels with 13 bytes per pixel of hit records in between; shade_kernel
+//                    rebuilds LightingData, samples the texture, sums Phong over the lights
+//                    and stores FP32 RGB + RGBA8 (transposed through LDS)
 //
 // Arithmetic of the decisions is the same as in the single-kernel path (rtk_kernels.hip):
 // conservative FP32 tests decide which (ray, object) pairs are looked at, then the
@@ -402,33 +401,6 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
   return in_shadow;
 }
 
-// Kernels 1+2 fused (every light has w = 0): camera ray, then the shadow rays of its hit.
-template <int KW>
-__global__ void __launch_bounds__(kBlock, 4) trace_uniform_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
-                                                                 const float4* __restrict__ prim_ball,
-                                                                 const float4* __restrict__ prim_cluster, RenderTarget T,
-                                                                 OpaqueBuffers B, DevCounters* counters) {
-  const PixelRef px = pixel_ref(T, C, T.n_local_tiles - 1u - blockIdx.x);
-  Closest best;
-  unsigned n_exact = 0;
-  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, n_exact);
-  const uint32_t obj = px.valid ? best.obj : 0xffffffffu;
-  const bool hit = obj != 0xffffffffu;
-  B.hit_obj[px.local] = obj;
-  B.hit_t[px.local] = best.t;
-  V3 p = {0, 0, 0};
-  if (hit) p = over_point(S, C, px, obj, best.t);
-  unsigned rays = 0;
-  const bool in_shadow = shadow_phase_uniform<KW>(S, hit, p, rays, n_exact);
-  B.shadow[px.local] = (uint8_t)((in_shadow ? 0x80u : 0u) | rays);
-  const unsigned n_primary = wave_sum(px.valid ? 1u : 0u);
-  n_exact = wave_sum(n_exact);
-  if ((threadIdx.x & 63u) == 0) {
-    atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)n_primary);
-    atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
-  }
-}
-
 // Kernel 2b: shadow rays for arbitrary lights (some w != 0): one pixel per lane, per-lane
 // line directions, LB lights fused.
 template <int LB>
@@ -564,13 +536,11 @@ hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCame
   if (T.n_local_tiles == 0) return after_rays ? hipEventRecord(after_rays, st) : hipSuccess;
   const dim3 tiles(T.n_local_tiles), block(kBlock);
   if (S.max_depth > 0) {
-    if (S.lights_uniform && S.k_width == 4) {
-      // up to 4 lights: everything in one kernel (128 VGPRs hold it without spills)
+    if (S.lights_uniform) {
+      // everything in one kernel; lights are swept in batches of 4 (the cluster levels cost next
+      // to nothing per batch, and 128 VGPRs hold the 4-light filter state without spills)
       hipLaunchKernelGGL((render_uniform_kernel<4>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, counters);
       return after_rays ? hipEventRecord(after_rays, st) : hipGetLastError();
-    } else if (S.lights_uniform) {
-      // 5 to 64 lights in batches of 8: the wider filter state does not leave room for the shading code
-      hipLaunchKernelGGL((trace_uniform_kernel<8>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);
     } else {
       hipLaunchKernelGGL(primary_kernel, tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);
       switch (light_batch_for(S.n_lights)) {

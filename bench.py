@@ -187,13 +187,16 @@ def main():
                 "rays_per_launch": int(local_rays),
                 "kernel_ms": avg_rays_ms,
                 "all_kernels_ms": avg_kernel_ms,
+                "measured_valu_busy": measured.get("valu_busy"),
+                "measured_valu_lane_util": measured.get("valu_lane_util"),
                 "measured_valu_issue_util": measured.get("valu_issue_util"),
                 "note": "achieved = algorithmic flops of the reference's sweep (26 per ray-sphere test, 8 per ray-plane "
                         "test, every ray against every object) / HIP-event time of the kernel that traces the rays "
                         "(for up to 4 lights it also shades and stores: kernel_ms = all_kernels_ms). The kernel culls "
                         "whole clusters of spheres per wavefront and executes far fewer instructions than that count, "
-                        "so the fraction exceeds 1; measured_valu_issue_util (rocprofv3 PMC, profiles/) is the share of "
-                        "SIMD issue cycles the kernel really uses",
+                        "so the fraction exceeds 1; measured_valu_busy (rocprofv3 PMC, profiles/: SQ_ACTIVE_INST_VALU x 4 / "
+                        "SIMD cycles) is the share of time the vector ALUs are really executing (mostly f64, 4 cycles "
+                        "per wave64 instruction), measured_valu_lane_util the share of lanes active in them",
             },
         }
         if world == 1 and not args.no_extra:

@@ -31,11 +31,27 @@ for name, counters in sorted(agg.items()):
             d["clock_GHz"] = cyc / (d["avg_ms"] * 1e6)
         simd_cycles = 1024.0 * cyc
         if "SQ_INSTS_VALU" in m:
-            d["valu_issue_util"] = m["SQ_INSTS_VALU"] * 2.0 / simd_cycles   # one wave64 VALU instruction = 2 cycles of a SIMD
+            d["valu_issue_util"] = m["SQ_INSTS_VALU"] * 2.0 / simd_cycles   # as if every wave64 VALU instruction took 2 cycles (FP32 rate)
+        if "SQ_ACTIVE_INST_VALU" in m:
+            # SQ_ACTIVE_INST_* count quad-cycles: time the SIMDs' vector ALUs are executing, whatever the
+            # instruction costs (FP32 2 cycles, f64 4, f64 rcp/sqrt 16 per wave64)
+            d["valu_busy"] = m["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles
+            if "SQ_THREAD_CYCLES_VALU" in m and m["SQ_ACTIVE_INST_VALU"] > 0:
+                d["valu_lane_util"] = m["SQ_THREAD_CYCLES_VALU"] / (m["SQ_ACTIVE_INST_VALU"] * 64.0)
         if "SQ_WAVE_CYCLES" in m:
             d["avg_waves_per_simd"] = m["SQ_WAVE_CYCLES"] * 4.0 / simd_cycles
         if "SQ_LDS_IDX_ACTIVE" in m:
             d["lds_busy"] = m["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc)
+    if "SQ_INSTS_VALU_FMA_F64" in m and "GRBM_GUI_ACTIVE" in m and m["GRBM_GUI_ACTIVE"] > 0:
+        # Instruction mix -> time the vector ALUs are executing.  Per wave64 instruction: f64
+        # add/mul/fma 4 cycles, f64 transcendental (rcp, rsq, sqrt) 16, everything else
+        # (FP32, integer, conversions, moves, compares) 2.
+        f64 = m.get("SQ_INSTS_VALU_ADD_F64", 0) + m.get("SQ_INSTS_VALU_MUL_F64", 0) + m["SQ_INSTS_VALU_FMA_F64"]
+        t64 = m.get("SQ_INSTS_VALU_TRANS_F64", 0)
+        t32 = m.get("SQ_INSTS_VALU_TRANS_F32", 0)
+        rest = m["SQ_INSTS_VALU"] - f64 - t64 - t32
+        d["f64_share_of_valu_insts"] = (f64 + t64) / m["SQ_INSTS_VALU"]
+        d["valu_busy_from_mix"] = (4.0 * f64 + 16.0 * t64 + 8.0 * t32 + 2.0 * rest) / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0)
     if "SQ_WAVES" in m and "SQ_INSTS_VALU" in m:
         d["valu_per_wave"] = m["SQ_INSTS_VALU"] / m["SQ_WAVES"]
     out[name] = d
@@ -62,6 +78,10 @@ if "--measured" in sys.argv:
         "write_bytes": int(d.get("WRITE_SIZE", 0.0) * 1024),
         "fetch_bytes_corrected": int(2.0 * d.get("FETCH_SIZE", 0.0) * 1024),
         "valu_issue_util": d.get("valu_issue_util"),
+        "valu_busy_quad_cycles": d.get("valu_busy"),
+        "valu_busy": d.get("valu_busy_from_mix"),
+        "f64_share_of_valu_insts": d.get("f64_share_of_valu_insts"),
+        "valu_lane_util": d.get("valu_lane_util"),
         "avg_waves_per_simd": d.get("avg_waves_per_simd"),
         "clock_GHz": d.get("clock_GHz"),
         "source": src,

@@ -147,6 +147,7 @@ struct rtk_scene_handle {
   void* d_exact = nullptr;
   void* d_sph_object = nullptr;
   void* d_plane_object = nullptr;
+  void* d_light_kind = nullptr;
   void* d_pattern_inv = nullptr;
   float4* d_prim = nullptr;  // primary-ray filter records (rebuilt per camera)
   float4* d_prim_ball = nullptr;  // camera-ray records of the wavefront-level cone test (rebuilt per camera)
@@ -301,7 +302,7 @@ void rtk_scene_release(rtk_context* ctx, rtk_scene_handle* h) {
   if (!h) return;
   if (ctx) (void)hipSetDevice(ctx->device);
   void* ptrs[] = {h->d_objects, h->d_lights, h->d_filter, h->d_exact, h->d_sph_object, h->d_plane_object, h->d_prim,
-                  h->d_light_filter, h->d_k_table, h->d_sph_tab, h->d_prim_ball, h->d_sph_ball, h->d_cluster_ball, h->d_prim_cluster, h->d_pattern_inv};
+                  h->d_light_filter, h->d_k_table, h->d_sph_tab, h->d_prim_ball, h->d_sph_ball, h->d_cluster_ball, h->d_prim_cluster, h->d_pattern_inv, h->d_light_kind};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -485,17 +486,29 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   // Lights with w == 0 (what scene files produce, src/loader.rs:35-40): the shadow-ray line
   // direction G = L.xyz does not depend on the shading point, so the per-(sphere, light)
   // part of the filter, K = c.g - R'^2 rho, is tabulated here.
-  bool lights_uniform = scene->n_lights > 0;
+  // Lights with w == 1 (built from points): plain segments from the shading point to the light;
+  // the bundle of a patch is a cone with its apex at the light.  Their record is the light's
+  // position, recentred like the sphere records.  lights_bundled: every light is one or the other.
+  bool lights_uniform = scene->n_lights > 0, lights_bundled = scene->n_lights > 0;
   std::vector<float4> light_filter(scene->n_lights);
+  std::vector<uint32_t> light_kind(scene->n_lights, 2u);  // 0: w == 0, 1: w == 1, 2: anything else
   std::vector<double> gd(4 * (size_t)scene->n_lights);
   for (uint32_t k = 0; k < scene->n_lights; ++k) {
     const double* L = scene->lights[k].position;
     const double gg = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
+    if (L[3] == 1.0 && std::isfinite(gg)) {
+      lights_uniform = false;
+      light_kind[k] = 1u;
+      light_filter[k] = make_float4((float)(L[0] - center[0]), (float)(L[1] - center[1]), (float)(L[2] - center[2]), 0.f);
+      continue;
+    }
     if (L[3] != 0.0 || !(gg > 0.0) || !std::isfinite(gg)) {
       lights_uniform = false;
+      lights_bundled = false;
       light_filter[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       continue;
     }
+    light_kind[k] = 0u;
     const double inv = 1.0 / std::sqrt(gg);
     gd[4 * k + 0] = L[0] * inv;
     gd[4 * k + 1] = L[1] * inv;
@@ -545,6 +558,7 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   upload(&h->d_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
   upload(&h->d_pattern_inv, pattern_inv.data(), pattern_inv.size() * sizeof(double));
   upload(&h->d_light_filter, light_filter.data(), light_filter.size() * sizeof(float4));
+  upload(&h->d_light_kind, light_kind.data(), light_kind.size() * sizeof(uint32_t));
   upload(&h->d_k_table, k_table.data(), k_table.size() * sizeof(float));
   upload(&h->d_sph_tab, sph_tab.data(), sph_tab.size() * sizeof(float4));
   upload(&h->d_sph_ball, sph_ball.data(), sph_ball.size() * sizeof(float4));
@@ -565,12 +579,14 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   d.plane_object = (const uint32_t*)h->d_plane_object;
   d.pattern_inv = (const double*)h->d_pattern_inv;
   d.light_filter = (const float4*)h->d_light_filter;
+  d.light_kind = (const uint32_t*)h->d_light_kind;
   d.k_table = (const float4*)h->d_k_table;
   d.sph_tab = (const float4*)h->d_sph_tab;
   d.sph_ball = (const float4*)h->d_sph_ball;
   d.cluster_ball = (const float4*)h->d_cluster_ball;
   d.n_clusters_padded = n_clusters_pad;
   d.lights_uniform = lights_uniform ? 1u : 0u;
+  d.lights_bundled = lights_bundled ? 1u : 0u;
   d.k_width = k_width;
   d.n_objects = scene->n_objects;
   d.n_lights = scene->n_lights;

@@ -52,7 +52,8 @@ struct DevScene {
   const uint32_t* sph_object;   // filter record -> object index
   const uint32_t* plane_object; // plane list -> object index
   const double* pattern_inv;    // per object, rows 0..2 of the inverse pattern transform (12 f64); null when no pattern has one
-  const float4* light_filter;   // per light: unit line direction g = G/|G| and rho = (w-1)/|G| for G = L.xyz (w = 0 lights)
+  const float4* light_filter;   // per light: w = 0: unit line direction g = L/|L| and rho = -1/|L|; w = 1: position minus DevScene::center
+  const uint32_t* light_kind;   // per light: 0 (w == 0), 1 (w == 1), 2 (anything else)
   const float4* k_table;        // [batch][sphere][k_width]: c_j.g_k - R_j'^2 rho_k, only when lights_uniform
   const float4* sph_tab;        // {cx, cy, cz, kappa |c|^2 - R'^2}: sphere record of the tabulated shadow filter
   const float4* sph_ball;       // {cx, cy, cz, R'}: record of the wavefront-level test; padding has R' = -1e30
@@ -64,6 +65,7 @@ struct DevScene {
   uint32_t track_n1;     // some transparent object has refractivity != the others: keep n1
   uint32_t any_secondary; // some material reflects or transmits: rays recurse
   uint32_t lights_uniform; // every light has w == 0: shadow-ray line directions do not depend on the shading point
+  uint32_t lights_bundled; // every light has w == 0 or w == 1: the shadow rays of a patch form lines / cones
   uint32_t k_width;        // lights per k_table row (4 or 8)
   double center[3];      // recentring offset of the FP32 filter
   double ambient[3];

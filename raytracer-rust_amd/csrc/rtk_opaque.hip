@@ -5,7 +5,9 @@
 //   render_uniform_kernel  every light has w = 0 (what scene files give): camera ray, the
 //                    shadow rays of its hit towards all lights (batches of 4), shading and
 //                    the store, in one kernel; nothing but the framebuffer crosses HBM
-//   primary_kernel + shadow_general_kernel + shade_kernel   when some light has w != 0:
+//   render_uniform_kernel<4, false>  the same when some lights have w = 1 (built from points):
+//                    their shadow rays form cones with the apex at the light
+//   primary_kernel + shadow_general_kernel + shade_kernel   when some light has another w:
 //                    camera rays, shadow rays (per-ray cluster walk) and shading as three
 //                    kernels with 13 bytes per pixel of hit records in between; shade_kernel
 //                    rebuilds LightingData, samples the texture, sums Phong over the lights
@@ -421,6 +423,173 @@ __global__ void __launch_bounds__(kBlock, 4) shadow_general_kernel(DevScene S, D
 }
 
 // ------------------------------------------------------------------------------------
+// Shadow phase when every light has w == 0 or w == 1 but not all have w == 0.  The shadow
+// rays of a patch towards a w == 1 light are segments from the ball {m, rho_w} of shading
+// points to the light: a cone with its apex AT THE LIGHT (the camera-ray test with the light
+// in place of the camera).  Level 2 uses the general per-ray form with the line direction
+// rebuilt per lane: g = L/|L| for w == 0, (L - p)/|L - p| for w == 1 (rho = 0).
+template <int KW>
+__device__ __forceinline__ bool shadow_phase_bundled(const DevScene& S, bool need, V3 p, unsigned& n_rays, unsigned& n_exact) {
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned rays = 0;
+  bool in_shadow = false;
+  for (uint32_t kb = 0; kb < S.n_lights; kb += KW) {
+    if (!wave_any(need)) break;
+    const uint32_t nb = min((uint32_t)KW, S.n_lights - kb);
+    uint32_t occl = 0;
+    bool live = false;
+    if (need) {
+      for (uint32_t r = 0; r < nb; ++r)
+        for (uint32_t ip = 0; ip < S.n_planes; ++ip)
+          if (plane_may_block(S.objects[S.plane_object[ip]], S.lights[kb + r], p) &&
+              shadow_ray_blocked(S.objects[S.plane_object[ip]], S.lights[kb + r], p))
+            occl |= 1u << r;
+      live = !(occl & 1u);
+    }
+    const V3 pc = {p.x - S.center[0], p.y - S.center[1], p.z - S.center[2]};
+    const float fx = (float)pc.x, fy = (float)pc.y, fz = (float)pc.z;
+    const Ball ball = make_ball(live, fx, fy, fz);
+
+    // per light (wavefront-uniform): line direction or cone; a short batch repeats its last light
+    float ax[KW], ay[KW], az[KW];  // w == 0: g; w == 1: cone axis
+    float bx[KW], by[KW], bz[KW];  // w == 1: apex (the light, recentred)
+    float lt[KW], ls[KW];          // w == 0: |rho|, unused; w == 1: tan, sec of the cone's half-angle
+    float rho[KW];                 // signed rho of the per-ray filter (0 for w == 1)
+    uint32_t cones = 0, open_cones = 0;  // bit k: light k has w == 1 / its cone is everything (light inside the ball)
+    float grow = 0.0f, rho_max = 0.0f, apex_max = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      const uint32_t li = kb + min((uint32_t)k, nb - 1u);
+      const float4 lf = S.light_filter[li];
+      if (S.light_kind[li] == 1u) {
+        cones |= 1u << k;
+        bx[k] = lf.x, by[k] = lf.y, bz[k] = lf.z;
+        const float ex = ball.mx - lf.x, ey = ball.my - lf.y, ez = ball.mz - lf.z;
+        const float D = sqrtf(ex * ex + ey * ey + ez * ez);
+        const float rw = ball.radius * (1.0f + 1.0e-5f) + 8.0f * kEps32 * (fabsf(lf.x) + fabsf(lf.y) + fabsf(lf.z) + D);
+        const float inv = 1.0f / fmaxf(D, 1.0e-30f);
+        ax[k] = ex * inv, ay[k] = ey * inv, az[k] = ez * inv;
+        const float leg2 = D * D - rw * rw;  // squared tangent length from the light to the ball
+        if (!(leg2 > 1.0e-6f * D * D)) open_cones |= 1u << k;
+        const float tn = rw / sqrtf(fmaxf(leg2, 1.0e-30f)) * (1.0f + 1.0e-5f) + 2.0e-6f;
+        lt[k] = tn;
+        ls[k] = sqrtf(1.0f + tn * tn) * (1.0f + 1.0e-6f);
+        rho[k] = 0.0f;
+        apex_max = fmaxf(apex_max, fabsf(lf.x) + fabsf(lf.y) + fabsf(lf.z));
+      } else {
+        ax[k] = lf.x, ay[k] = lf.y, az[k] = lf.z;
+        bx[k] = by[k] = bz[k] = 0.0f;
+        lt[k] = fabsf(lf.w) * 1.0001f;
+        ls[k] = 0.0f;
+        rho[k] = lf.w;
+        rho_max = fmaxf(rho_max, fabsf(lf.w) * 1.0001f);
+        grow = fmaxf(grow, 0.5f * S.r_max * S.r2_max * lf.w * lf.w);
+      }
+    }
+    const float slack = 16.0f * kEps32 * (fabsf(ball.mx) + fabsf(ball.my) + fabsf(ball.mz) + ball.radius + S.c_max + apex_max);
+    const float pad = ball.radius + grow * 1.01f + slack;
+    // per-lane threshold of the level-2 filter
+    const float thr = need ? filter_threshold(S, pc, rho_max) : 3.0e38f;
+
+    // rec = {centre, radius} of a sphere (t_extra = 0, growth radius = its own) or of a
+    // cluster (t_extra = its radius, growth radius = the scene's largest sphere radius)
+    auto bundles_reach = [&](float4 rec, float t_extra, float r_grow) {
+      bool pass = false;
+#pragma unroll
+      for (int k = 0; k < KW; ++k) {
+        if ((cones >> k) & 1u) {
+          if ((open_cones >> k) & 1u) {
+            pass |= rec.w >= 0.0f;  // every real record; padding records carry a negative radius
+          } else {
+            const float lx = rec.x - bx[k], ly = rec.y - by[k], lz = rec.z - bz[k];
+            const float s = __builtin_fmaf(lz, az[k], __builtin_fmaf(ly, ay[k], lx * ax[k]));
+            const float qx = __builtin_fmaf(-s, ax[k], lx), qy = __builtin_fmaf(-s, ay[k], ly), qz = __builtin_fmaf(-s, az[k], lz);
+            const float d2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+            const float rr = __builtin_fmaf(s, lt[k], (rec.w + slack) * ls[k]) * (1.0f + 4.0f * kEps32);
+            pass |= rr >= 0.0f && __builtin_fmaf(rr, rr, -d2) >= 0.0f;
+          }
+        } else {
+          const float ux = ball.mx - rec.x, uy = ball.my - rec.y, uz = ball.mz - rec.z;
+          const float s = __builtin_fmaf(uz, az[k], __builtin_fmaf(uy, ay[k], ux * ax[k]));
+          const float qx = __builtin_fmaf(-s, ax[k], ux), qy = __builtin_fmaf(-s, ay[k], uy), qz = __builtin_fmaf(-s, az[k], uz);
+          const float d2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+          const float t = fmaxf(ball.radius + t_extra - s, 0.0f) * (1.0f + 8.0f * kEps32);
+          const float rr = __builtin_fmaf(t, r_grow * lt[k], rec.w + pad) * (1.0f + 4.0f * kEps32);
+          pass |= rr >= 0.0f && __builtin_fmaf(rr, rr, -d2) >= 0.0f;
+        }
+      }
+      return pass;
+    };
+
+    bool wave_live = wave_any(live);
+    for (uint32_t cbase = 0; wave_live && cbase < S.n_clusters_padded; cbase += kBundle) {
+      const float4 cl = S.cluster_ball[cbase + lane];
+      unsigned long long cm = __builtin_amdgcn_ballot_w64(bundles_reach(cl, cl.w, S.r_max));
+      for (; wave_live && cm != 0ull; cm &= cm - 1ull) {
+        const uint32_t first = (cbase + (uint32_t)__builtin_ctzll(cm)) * kBundle;
+        const float4 rec = S.sph_ball[first + lane];
+        unsigned long long m = __builtin_amdgcn_ballot_w64(bundles_reach(rec, 0.0f, rec.w));
+        bool changed = false;
+        // level 2: the general per-ray filter (see sweep_filter in rtk_sweeps.h), then the exact test
+        for (; m != 0ull; m &= m - 1ull) {
+          const uint32_t j = first + (uint32_t)__builtin_ctzll(m);
+          const float4 c = S.sph_filter[j];
+          const float ux = fx - c.x, uy = fy - c.y, uz = fz - c.z;
+          const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+          const float cf = __builtin_fmaf(uu, kKappa, -c.w);
+          uint32_t mask = 0;
+#pragma unroll
+          for (int k = 0; k < KW; ++k) {
+            float h;
+            if ((cones >> k) & 1u) {
+              // direction from the f64 difference, normalised in FP32 (rsq: 1 ulp); the factor on h^2
+              // below covers the direction's length being off by a few ulp
+              const DevLight& L = S.lights[kb + min((uint32_t)k, nb - 1u)];
+              const float gx = (float)(L.pos[0] - p.x), gy = (float)(L.pos[1] - p.y), gz = (float)(L.pos[2] - p.z);
+              const float gg = __builtin_fmaf(gz, gz, __builtin_fmaf(gy, gy, gx * gx));
+              h = __builtin_fmaf(uz, gz, __builtin_fmaf(uy, gy, ux * gx)) * __builtin_amdgcn_rsqf(gg);
+              if (!(gg > 0.0f && gg < 3.0e38f)) h = 3.0e18f;  // light at the shading point, or out of FP32 range: leave it to the exact test
+            } else {
+              h = __builtin_fmaf(uz, az[k], __builtin_fmaf(uy, ay[k], __builtin_fmaf(ux, ax[k], c.w * rho[k])));
+            }
+            if (__builtin_fmaf(h * (1.0f + 16.0f * kEps32), h, -cf) >= thr) mask |= 1u << k;
+          }
+          if (!live) mask = 0;
+          mask &= ~occl;
+          if (wave_any(mask != 0)) {
+            const DevObject& ob = S.objects[S.sph_object[j]];
+            if (mask) {
+              for (uint32_t r = 0; r < nb; ++r)
+                if ((mask >> r) & 1u) {
+                  ++n_exact;
+                  if (shadow_ray_blocked(ob, S.lights[kb + r], p)) occl |= 1u << r;
+                }
+            }
+            changed = true;
+          }
+        }
+        if (changed) {
+          if (live && (occl & 1u)) live = false;
+          wave_live = wave_any(live);
+        }
+      }
+    }
+    if (need) {
+      occl &= (nb >= 32u) ? 0xffffffffu : ((1u << nb) - 1u);
+      if (occl) {
+        rays += (unsigned)__builtin_ctz(occl) + 1u;
+        in_shadow = true;
+        need = false;
+      } else {
+        rays += nb;
+      }
+    }
+  }
+  n_rays += rays;
+  return in_shadow;
+}
+
+// ------------------------------------------------------------------------------------
 // `apply_lighting` (src/scene.rs:172-205) for a hit on an opaque material: the reflected and
 // refracted parts are BLACK, what is left is ambient + the Phong sum over the lights.
 __device__ __forceinline__ V3 shade_hit(const DevScene& S, const DevCamera& C, const PixelRef& px, uint32_t obj, double t,
@@ -498,7 +667,7 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, 
 }
 
 // All three steps in one kernel (every light has w = 0): no hit records cross HBM.
-template <int KW>
+template <int KW, bool TABULATED>
 __global__ void __launch_bounds__(kBlock, 4) render_uniform_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                                   const float4* __restrict__ prim_ball,
                                                                   const float4* __restrict__ prim_cluster, RenderTarget T,
@@ -515,7 +684,8 @@ __global__ void __launch_bounds__(kBlock, 4) render_uniform_kernel(DevScene S, D
   V3 p = {0, 0, 0};
   if (hit) p = over_point(S, C, px, obj, best.t);
   unsigned rays = 0;
-  const bool in_shadow = shadow_phase_uniform<KW>(S, hit, p, rays, n_exact);
+  const bool in_shadow = TABULATED ? shadow_phase_uniform<KW>(S, hit, p, rays, n_exact)
+                                   : shadow_phase_bundled<KW>(S, hit, p, rays, n_exact);
   V3 color = {0, 0, 0};
   if (px.valid) color = hit ? shade_hit(S, C, px, launder(obj), best.t, in_shadow) : ld3(S.ambient);
   store_tile(C, T, k, color, s_rgb, s_px);
@@ -539,7 +709,11 @@ hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCame
     if (S.lights_uniform) {
       // everything in one kernel; lights are swept in batches of 4 (the cluster levels cost next
       // to nothing per batch, and 128 VGPRs hold the 4-light filter state without spills)
-      hipLaunchKernelGGL((render_uniform_kernel<4>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, counters);
+      hipLaunchKernelGGL((render_uniform_kernel<4, true>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, counters);
+      return after_rays ? hipEventRecord(after_rays, st) : hipGetLastError();
+    } else if (S.lights_bundled) {
+      // some lights built from points (w == 1): same kernel with cones from those lights
+      hipLaunchKernelGGL((render_uniform_kernel<4, false>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, counters);
       return after_rays ? hipEventRecord(after_rays, st) : hipGetLastError();
     } else {
       hipLaunchKernelGGL(primary_kernel, tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);

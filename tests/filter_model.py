@@ -272,3 +272,30 @@ def camera_ray_reaches_cluster(directions, records):
     qx, qy, qz = fma(-s, dx, L[..., 0]), fma(-s, dy, L[..., 1]), fma(-s, dz, L[..., 2])
     d2 = fma(qz, qz, fma(qy, qy, (qx * qx).astype(F)))
     return (L[..., 3] * L[..., 3] * F(1.0 + 8.0 * float(EPS32))).astype(F) >= d2
+
+
+# ---- cone of shadow rays towards a w = 1 light (shadow_phase_bundled in csrc/rtk_opaque.hip) ------
+
+def light_cone_reaches(fs, ball, light_xyz, rec):
+    """Patch ball = make_ball(...) of recentred points, one w = 1 light at light_xyz (world, f64),
+    rec [n, 4] sphere or cluster records; True where a segment point -> light may touch the record."""
+    m, radius = ball
+    lf = (np.asarray(light_xyz, np.float64) - fs.center).astype(F)
+    e = (m - lf).astype(F)
+    D = np.sqrt(F(e[0] * e[0] + e[1] * e[1] + e[2] * e[2])).astype(F)
+    apex_max = F(abs(lf[0]) + abs(lf[1]) + abs(lf[2]))
+    rw = F(radius * F(1.0 + 1.0e-5) + F(8.0) * EPS32 * (apex_max + D))
+    inv = F(1.0) / max(D, F(1.0e-30))
+    a = (e * inv).astype(F)
+    leg2 = F(D * D - rw * rw)
+    slack = F(F(16.0) * EPS32 * (abs(m[0]) + abs(m[1]) + abs(m[2]) + radius + fs.c_max + apex_max))
+    if not (leg2 > F(1.0e-6) * D * D):
+        return rec[:, 3] >= 0
+    tn = F(rw / np.sqrt(max(leg2, F(1.0e-30))) * F(1.0 + 1.0e-5) + F(2.0e-6))
+    sec = F(np.sqrt(F(1.0) + tn * tn) * F(1.0 + 1.0e-6))
+    lx, ly, lz = (rec[:, 0] - lf[0]).astype(F), (rec[:, 1] - lf[1]).astype(F), (rec[:, 2] - lf[2]).astype(F)
+    s = fma(lz, a[2], fma(ly, a[1], (lx * a[0]).astype(F)))
+    qx, qy, qz = fma(-s, a[0], lx), fma(-s, a[1], ly), fma(-s, a[2], lz)
+    d2 = fma(qz, qz, fma(qy, qy, (qx * qx).astype(F)))
+    rr = (fma(s, tn, ((rec[:, 3] + slack) * sec).astype(F)) * F(1.0 + 4.0 * float(EPS32))).astype(F)
+    return (rr >= 0) & (fma(rr, rr, -d2) >= 0)

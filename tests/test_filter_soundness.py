@@ -334,3 +334,51 @@ def test_camera_ray_cluster_test_keeps_every_grazing_hit(scale):
         own = reach[np.arange(n), np.arange(n)]
         assert not (hit & ~own).any(), f"dropped {int((hit & ~own).sum())} at delta={delta}"
     assert scale < 50 or reach.mean() < 0.5
+
+
+# ---- cone of shadow rays towards a light built from a point (w = 1) -----------------------------
+from filter_model import light_cone_reaches
+
+
+@pytest.mark.parametrize("scale", [3.0, 60.0, 1500.0])
+def test_light_cone_keeps_every_sphere_some_shadow_ray_of_the_patch_grazes(scale):
+    rng = np.random.default_rng(int(scale) + 41)
+    skipped_any = False
+    for trial in range(60):
+        n = 64
+        centre = rng.normal(size=3) * scale * 0.4
+        spread = 10.0 ** rng.uniform(-3, 0.3)
+        pts = centre + rng.normal(size=(n, 3)) * spread
+        # the light anywhere from inside the patch's ball to far away
+        L = centre + _unit(rng.normal(size=3)) * spread * 10.0 ** rng.uniform(-0.5, 3.0)
+        lv = L - pts
+        mlen = np.sqrt((lv * lv).sum(axis=1))          # w = 1: the direction's w is 0
+        d, dw = lv / mlen[:, None], np.zeros(n)
+        s = rng.uniform(0.02, 0.98, size=(n, 1))        # occluders between point and light
+        c = pts + lv * s + rng.normal(size=(n, 3)) * rng.uniform(0.01, 3.0, size=(n, 1))
+        Rstar = grazing_radius(pts, d, dw, c)
+        for delta in (1e-13, 1e-8, 1e-3):
+            R = Rstar * (1.0 + delta)
+            # the cone is one-sided: what counts is a root inside the segment, 0 < t < m
+            # (src/scene.rs:217-222), not one on the line beyond the light
+            oo, dd = (pts - c) / R[:, None], d / R[:, None]
+            qa, qb, qc = (dd * dd).sum(axis=1), 2.0 * (oo * dd).sum(axis=1), (oo * oo).sum(axis=1) - 1.0
+            disc = qb * qb - 4.0 * qa * qc
+            root = np.sqrt(np.maximum(disc, 0.0))
+            t0, t1 = (-qb - root) / (2.0 * qa), (-qb + root) / (2.0 * qa)
+            hit = (disc >= 0) & (((t0 > 0) & (t0 < mlen)) | ((t1 > 0) & (t1 < mlen)))
+            fs = FilterScene(c, R)
+            ball = make_ball((pts - fs.center).astype(np.float32))
+            balls = sphere_balls(fs)
+            keep = light_cone_reaches(fs, ball, L, balls)
+            assert not (hit & ~keep).any(), (trial, delta)
+            cl = cluster_balls(balls[:, :3], balls[:, 3])
+            assert light_cone_reaches(fs, ball, L, cl).all() or not hit.any()
+            skipped_any |= bool((~keep).any())
+            seen_hits = hit.any()
+    # padding records (negative radius) never pass, not even when the light sits inside the ball
+    fs = FilterScene(np.zeros((2, 3)) + [[0, 0, 0], [5, 0, 0]], np.ones(2))
+    pad = np.array([[0, 0, 0, -1e30]], np.float32)
+    for light in ([0.1, 0.0, 0.0], [50.0, 3.0, 1.0]):
+        ball = make_ball(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32))
+        assert not light_cone_reaches(fs, ball, light, pad).any()

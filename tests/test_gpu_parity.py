@@ -414,3 +414,20 @@ def test_fifty_thousand_spheres(rtk, dev, oracle):
     scene = rtk.synthetic.make_scene(50000, True, 4, 555)
     camera = rtk.synthetic.make_camera(50000, 96, 54)
     check_against_oracle(dev, oracle, scene, camera, "50,000 spheres")
+
+
+def test_point_lights_inside_the_field(rtk, dev, oracle):
+    """w = 1 lights between the spheres and right above the floor: for patches next to a light the
+    cone of shadow rays opens up to everything (the light lies inside the ball of shading points)."""
+    rng = np.random.default_rng(31)
+    E = 10.0
+    lights = [rtk.point(0.3, 0.8, 9.0), rtk.point(-4.0, 0.02, 5.0), rtk.point(2.0, 6.0, 14.0)]
+    scene = _random_field(rtk, rng, 500, True, 0.15, 1.2, E, lights)
+    check_against_oracle(dev, oracle, scene, _field_camera(rtk, E, 192, 108), "point lights inside")
+    check_against_oracle(dev, oracle, scene, _field_camera(rtk, E, 128, 72, rtk.point(0.3, 2.0, 9.0), rtk.point(4, 0.5, 15)),
+                         "point lights inside, camera inside")
+    # one light of each kind in one batch, and more than one batch
+    scene.lights = [rtk.PointLight(rtk.vec3(-6, 18, -4), rtk.rgb(0.3, 0.3, 0.3)), rtk.PointLight(lights[0], rtk.rgb(0.3, 0.3, 0.3)),
+                    rtk.PointLight(rtk.vec3(7, 15, 25), rtk.rgb(0.2, 0.2, 0.2)), rtk.PointLight(lights[2], rtk.rgb(0.2, 0.2, 0.2)),
+                    rtk.PointLight(lights[1], rtk.rgb(0.2, 0.2, 0.2)), rtk.PointLight(rtk.vec3(0.5, 9, 3), rtk.rgb(0.2, 0.2, 0.2))]
+    check_against_oracle(dev, oracle, scene, _field_camera(rtk, E, 160, 90), "six mixed lights")

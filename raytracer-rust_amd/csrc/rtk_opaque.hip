@@ -136,6 +136,7 @@ __device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera
     unsigned long long cm = __builtin_amdgcn_ballot_w64(cone_reaches(cone, prim_cluster[cbase + lane]));
     for (; cm != 0ull; cm &= cm - 1ull) {
       const uint32_t first = (cbase + (uint32_t)__builtin_ctzll(cm)) * kBundle;
+      if (first >= S.n_spheres_padded) break;  // cannot happen (padding clusters never pass); keeps a slip from reading out of bounds
       // level 1: this lane's sphere of the cluster against the cone
       unsigned long long m = __builtin_amdgcn_ballot_w64(cone_reaches(cone, prim_ball[first + lane]));
       // level 2: per-ray filter and exact test for the spheres level 1 kept
@@ -345,6 +346,7 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
       unsigned long long cm = __builtin_amdgcn_ballot_w64(lines_reach(cl, cl.w, S.r_max));
       for (; wave_live && cm != 0ull; cm &= cm - 1ull) {
         const uint32_t first = (cbase + (uint32_t)__builtin_ctzll(cm)) * kBundle;
+        if (first >= S.n_spheres_padded) break;  // cannot happen (padding clusters never pass); keeps a slip from reading out of bounds
         // level 1: this lane's sphere of the cluster
         const float4 rec = S.sph_ball[first + lane];
         unsigned long long m = __builtin_amdgcn_ballot_w64(lines_reach(rec, 0.0f, rec.w));
@@ -527,6 +529,7 @@ __device__ __forceinline__ bool shadow_phase_bundled(const DevScene& S, bool nee
       unsigned long long cm = __builtin_amdgcn_ballot_w64(bundles_reach(cl, cl.w, S.r_max));
       for (; wave_live && cm != 0ull; cm &= cm - 1ull) {
         const uint32_t first = (cbase + (uint32_t)__builtin_ctzll(cm)) * kBundle;
+        if (first >= S.n_spheres_padded) break;  // cannot happen (padding clusters never pass); keeps a slip from reading out of bounds
         const float4 rec = S.sph_ball[first + lane];
         unsigned long long m = __builtin_amdgcn_ballot_w64(bundles_reach(rec, 0.0f, rec.w));
         bool changed = false;

@@ -92,9 +92,8 @@ def _worker(rank, world, port, w, h, out_path):
     tdist.destroy_process_group()
 
 
-@pytest.mark.parametrize("w,h", [(96, 40), (70, 19)])
-def test_two_rank_frame_equals_single_rank(rtk, oracle, tmp_path, w, h):
-    world = 2
+@pytest.mark.parametrize("world,w,h", [(2, 96, 40), (2, 70, 19), (3, 100, 30)])
+def test_multi_rank_frame_equals_single_rank(rtk, oracle, tmp_path, world, w, h):
     out = str(tmp_path / "frame.npz")
     mp.spawn(_worker, args=(world, _free_port(), w, h, out), nprocs=world, join=True)
     got = np.load(out)

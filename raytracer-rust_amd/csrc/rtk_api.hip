@@ -366,6 +366,9 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
     const rtk_object& src = scene->objects[i];
     if (src.kind != RTK_SPHERE && src.kind != RTK_PLANE) return fail(RTK_ERR_INVALID, "rtk_scene_upload: unknown object kind");
     if (src.material.texture_kind > RTK_TEX_STRIPED) return fail(RTK_ERR_INVALID, "rtk_scene_upload: unknown texture kind");
+    for (double v : src.transform)
+      if (!std::isfinite(v))  // the reference panics on the NaN distances such a transform produces (src/scene.rs:164-166)
+        return fail(RTK_ERR_INVALID, "rtk_scene_upload: object transform has a non-finite element");
     if (!is_affine(src.transform))
       return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: object transform is not affine (last row must be 0 0 0 1)");
     if (src.kind == RTK_PLANE && src.plane_normal[3] != 0.0)

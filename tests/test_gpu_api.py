@@ -51,6 +51,12 @@ def test_unsupported_inputs_are_rejected(rtk, dev, device_mod):
     with pytest.raises(device_mod.RtkError) as e:
         dev.upload(s)
     assert e.value.code == rtk.abi.RTK_ERR_INVALID
+    for poison in (float("nan"), float("inf")):
+        s = rtk.synthetic.config("C2", 64, 36)[0].to_abi()
+        s.objects[5].transform[3] = poison  # the reference panics on the NaN distances this gives (src/scene.rs:164-166)
+        with pytest.raises(device_mod.RtkError) as e:
+            dev.upload(s)
+        assert e.value.code == rtk.abi.RTK_ERR_INVALID and "non-finite" in str(e.value)
 
 
 def test_null_arguments(rtk, dev, device_mod):

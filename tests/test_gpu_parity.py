@@ -431,3 +431,13 @@ def test_point_lights_inside_the_field(rtk, dev, oracle):
                     rtk.PointLight(rtk.vec3(7, 15, 25), rtk.rgb(0.2, 0.2, 0.2)), rtk.PointLight(lights[2], rtk.rgb(0.2, 0.2, 0.2)),
                     rtk.PointLight(lights[1], rtk.rgb(0.2, 0.2, 0.2)), rtk.PointLight(rtk.vec3(0.5, 9, 3), rtk.rgb(0.2, 0.2, 0.2))]
     check_against_oracle(dev, oracle, scene, _field_camera(rtk, E, 160, 90), "six mixed lights")
+
+
+def test_randomised_scenes(rtk, dev, oracle):
+    """120 scenes drawn from wide ranges (tests/fuzz_parity.py): radii over three decades, fields far
+    from the origin, lights of every kind near and far, affine spheres, patterns, glass."""
+    from fuzz_parity import random_scene
+
+    for seed in range(2000, 2120):
+        scene, camera, what = random_scene(rtk, np.random.default_rng(seed))
+        check_against_oracle(dev, oracle, scene, camera, f"seed {seed}: {what}")

@@ -1,6 +1,6 @@
 """Randomised parity sweep of the HIP path against the CPU oracle (run by hand on a GPU box):
 
-    python tests/fuzz_parity.py [n_scenes] [seed]
+    python tests/fuzz_parity.py [n_scenes] [seed]          (FUZZ_BIG=1: thousands of spheres per scene)
 
 Scenes are drawn from wide ranges -- sphere radii over three decades, fields far from the origin,
 lights of every kind next to and far from the geometry, general affine transforms, every texture,
@@ -23,7 +23,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 def random_scene(rtk, rng):
     M, T = rtk.Matrix4x4, rtk.Texture
     scene = rtk.Scene()
-    n = int(rng.choice([3, 20, 70, 200, 600]))
+    n = int(rng.choice([2000, 5000, 12000] if os.environ.get("FUZZ_BIG") else [3, 20, 70, 200, 600]))
     extent = float(10.0 ** rng.uniform(0.3, 2.5))
     offset = rng.normal(size=3) * float(rng.choice([0.0, 0.0, 10.0, 3000.0]))
     r_lo, r_hi = extent * 10.0 ** rng.uniform(-3.0, -1.5), extent * 10.0 ** rng.uniform(-1.3, -0.3)

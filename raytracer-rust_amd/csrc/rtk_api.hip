@@ -644,7 +644,8 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
   t.rank = tl.rank;
   t.world = tl.world;
   const uint64_t n_local = rtk_tiles_for_rank(camera->width, camera->height, tl.rank, tl.world);
-  if (n_local > 0x7fffffffull) return fail(RTK_ERR_UNSUPPORTED, "rtk_render_device: frame has too many tiles");
+  // per-launch pixel indices (local tile * 256 + slot) are 32-bit
+  if (n_local > 0x00ffffffull) return fail(RTK_ERR_UNSUPPORTED, "rtk_render_device: more than 16,777,215 tiles (4.29e9 pixels) per launch");
   t.n_local_tiles = (uint32_t)n_local;
   t.compact = tl.world > 1 ? 1u : 0u;
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput benchmark of the ray-trace path (BASELINE.json: Mrays/s at 3840x2160).
+"""Throughput benchmark of the ray-trace path: Mrays/s at 3840x2160.
 
 A "step" renders one whole frame of the workload with the scene already resident in HBM:
 every rank traces its share of the 32x8 tiles, the compact tile buffers are gathered to
@@ -26,7 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 peak: 256 CUs x 2.4 GHz x 256 flop/clk/CU
-FLOPS_PER_SPHERE_TEST = 26  # algorithmic flops of one ray-sphere test
+FLOPS_PER_SPHERE_TEST = 26  # algorithmic flops of one ray-sphere test: oc = o-c 3, oc.d 5, oc.oc - r^2 6, disc 3, sqrt 1, two roots 4, two range tests 4
 FLOPS_PER_PLANE_TEST = 8
 
 

@@ -74,7 +74,7 @@ def test_synthetic_config_reduced_resolution(rtk, dev, oracle, name, w, h):
 @pytest.mark.parametrize("name,rect", [("C3", (1792, 1180, 2048, 1324)), ("C4", (1800, 1000, 1992, 1108)),
                                        ("C4", (0, 2060, 160, 2160))])
 def test_full_size_frame_crop(rtk, dev, oracle, name, rect):
-    """BASELINE.json's full sizes (3840x2160): the whole frame is rendered on the device, a
+    """The benchmark's full sizes (3840x2160): the whole frame is rendered on the device, a
     rectangle of it is checked against the oracle."""
     scene, camera = rtk.synthetic.config(name)
     check_against_oracle(dev, oracle, scene, camera, f"{name} crop {rect}", rect=rect)

@@ -186,6 +186,8 @@ def main():
                 "flops_per_ray": fpr,
                 "rays_per_launch": int(local_rays),
                 "kernel_ms": avg_rays_ms,
+                "framebuffer_store_GBps": (camera.width * camera.height * 16 / world) / (avg_kernel_ms * 1e-3) / 1e9
+                if avg_kernel_ms > 0 else None,  # sanity counter: 12 B FP32 RGB + 4 B RGBA8 per pixel, written once
                 "all_kernels_ms": avg_kernel_ms,
                 "measured_valu_busy": measured.get("valu_busy"),
                 "measured_valu_lane_util": measured.get("valu_lane_util"),

@@ -4,6 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 rtk = importlib.import_module("raytracer-rust_amd")
 device = importlib.import_module("raytracer-rust_amd.device")
+if os.environ.get("RTK_LIB"):  # A/B runs: another build of the library
+    device.LIB_PATH = os.path.abspath(os.environ["RTK_LIB"])
 dev = device.Device(0)
 names = sys.argv[1:] or ["C2", "C3", "C4"]
 for name in names:

@@ -189,7 +189,10 @@ class Camera {
   double half_width, half_height, field_of_view, pixel_size;
   Matrix4x4 transform;  // public in the reference (cameras.rs:14)
   rtk_camera pack() const;
-  Canvas render(const Scene& scene, Device& device) const;  // cameras.rs:72-85
+  // cameras.rs:72-85; samples_per_axis > 1 averages that many squared samples per pixel (the
+  // reference has one sample, through the pixel centre: cameras.rs:53-54)
+  Canvas render(const Scene& scene, Device& device, uint32_t samples_per_axis = 1) const;
+  Camera supersampled(uint32_t samples_per_axis) const;  // the camera whose pixels are this camera's samples
 };
 
 // Scene files (src/loader.rs:22-200).  The YAML subset a scene file uses: block mappings and

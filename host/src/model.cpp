@@ -124,12 +124,22 @@ rtk_camera Camera::pack() const {
   std::memcpy(c.transform, transform.e.data(), sizeof c.transform);
   return c;
 }
-Canvas Camera::render(const Scene& scene, Device& device) const {
+Camera Camera::supersampled(uint32_t samples_per_axis) const {
+  const rtk_camera c = pack();
+  rtk_camera fine{};
+  const int rc = rtk_camera_supersample(&c, samples_per_axis, &fine);
+  if (rc != RTK_OK) throw_last(rc, "rtk_camera_supersample");
+  Camera out = *this;
+  out.width = fine.width, out.height = fine.height, out.pixel_size = fine.pixel_size;
+  return out;
+}
+Canvas Camera::render(const Scene& scene, Device& device, uint32_t samples_per_axis) const {
   Scene::Packed packed;
   scene.pack(packed);
   const rtk_camera cam = pack();
   Canvas canvas(width, height);
-  const int rc = rtk_render(device.context(), &packed.scene, &cam, canvas.rgb_data(), canvas.rgba8_data(), &canvas.stats);
+  const int rc = rtk_render_sampled(device.context(), &packed.scene, &cam, samples_per_axis, canvas.rgb_data(),
+                                    canvas.rgba8_data(), &canvas.stats);
   if (rc != RTK_OK) throw_last(rc, "rtk_render");
   return canvas;
 }

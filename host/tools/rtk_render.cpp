@@ -1,7 +1,8 @@
 // rtk_render -- the reference's entry point (src/main.rs:12-24) on the GPU:
 //   load a scene file, Camera::new(1920, 1080, PI / 3), render, save_to_png("./output.png").
 //
-//   rtk_render [scene.yaml] [output.png] [--width W] [--height H] [--fov RADIANS] [--device N]
+//   rtk_render [scene.yaml] [output.png] [--width W] [--height H] [--fov RADIANS] [--device N] [--samples S]
+// --samples S averages S x S samples per pixel (the reference has one, src/scene/cameras.rs:53-54).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +16,7 @@ int main(int argc, char** argv) {
   uint32_t width = 1920, height = 1080;
   double fov = PI / 3.0;
   int device_id = 0, positional = 0;
+  uint32_t samples = 1;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto value = [&]() -> const char* {
@@ -28,10 +30,11 @@ int main(int argc, char** argv) {
     else if (a == "--height") height = (uint32_t)std::strtoul(value(), nullptr, 10);
     else if (a == "--fov") fov = std::strtod(value(), nullptr);
     else if (a == "--device") device_id = std::atoi(value());
+    else if (a == "--samples") samples = (uint32_t)std::strtoul(value(), nullptr, 10);
     else if (positional == 0) scene_path = a, ++positional;
     else if (positional == 1) out_path = a, ++positional;
     else {
-      std::fprintf(stderr, "usage: rtk_render [scene.yaml] [output.png] [--width W] [--height H] [--fov R] [--device N]\n");
+      std::fprintf(stderr, "usage: rtk_render [scene.yaml] [output.png] [--width W] [--height H] [--fov R] [--device N] [--samples S]\n");
       return 2;
     }
   }
@@ -39,7 +42,7 @@ int main(int argc, char** argv) {
     const Scene scene = PackedScene::from_yaml_file(scene_path).build();
     const Camera camera(width, height, fov);
     Device device(device_id);
-    const Canvas canvas = camera.render(scene, device);
+    const Canvas canvas = camera.render(scene, device, samples);
     canvas.save_to_png(out_path);
     const rtk_stats& s = canvas.stats;
     std::printf("%s: %ux%u, %zu objects, %zu lights -> %s\n", scene_path.c_str(), width, height, scene.nodes.size(),

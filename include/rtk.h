@@ -186,6 +186,34 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
 int rtk_render(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camera,
                float* rgb_f32_out, uint8_t* rgba8_out, rtk_stats* stats);
 
+/* ---- More than one sample per pixel.  No counterpart in the reference, which traces one ray
+ * through each pixel centre (src/scene/cameras.rs:53-54); samples_per_axis == 1 is that.
+ * With s = samples_per_axis the s*s samples of pixel (x, y) are the pixel centres
+ * (s*x + i, s*y + j), 0 <= i, j < s, of the camera rtk_camera_supersample() derives: the same
+ * view at s*width x s*height with pixel_size / s, so every sample is a ray the reference's
+ * `Camera::ray_for_pixel` (src/scene/cameras.rs:52-69) would produce for that camera.  The
+ * pixel is the mean of its samples' FP32 colours, summed in f64 in row-major order (j outer,
+ * i inner) and divided by s*s; the mean is narrowed to FP32 and cast to 8 bits exactly as a
+ * single colour is. */
+#define RTK_MAX_SAMPLES_PER_AXIS 16
+int rtk_camera_supersample(const rtk_camera* camera, uint32_t samples_per_axis, rtk_camera* out);
+
+/* rtk_render_device with s*s samples per pixel (whole frame, row-major device outputs; the
+ * sample frame lives in a buffer of the context that grows on demand).  Ray counts and
+ * kernel times of the call cover all samples and the averaging kernel. */
+int rtk_render_device_sampled(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera,
+                              uint32_t samples_per_axis, float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream);
+
+/* rtk_render with s*s samples per pixel (host outputs). */
+int rtk_render_sampled(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camera, uint32_t samples_per_axis,
+                       float* rgb_f32_out, uint8_t* rgba8_out, rtk_stats* stats);
+
+/* The averaging step alone: d_samples_rgb_f32 holds (s*width) x (s*height) x 3 floats (what
+ * rtk_render_device writes for the supersampled camera), outputs as rtk_render_device's.
+ * Device pointers; either output may be NULL. */
+int rtk_resolve(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t samples_per_axis,
+                const float* d_samples_rgb_f32, float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream);
+
 /* `Scene::trace(&self, ray: Ray) -> Color` (src/scene.rs:136-138) for n caller-supplied
  * rays: origins and directions are n x 4 doubles (x, y, z, w), colors_out n x 3 doubles.
  * All three are HOST pointers; the call synchronises.  Origins must have w = 1 and

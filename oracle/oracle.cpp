@@ -852,4 +852,39 @@ int oracle_render(const rtk_scene* scene, const rtk_camera* camera, uint32_t x0,
   return 0;
 }
 
+// More than one sample per pixel.  The reference has none of this (one ray through each
+// pixel centre, cameras.rs:53-54); the definition restated here is the one of include/rtk.h:
+// the samples of pixel (x, y) are the pixels (s x + i, s y + j) of the same camera at s times
+// the resolution (pixel_size / s), each traced as the reference traces a pixel; their colours
+// are narrowed to FP32, summed in f64 in row-major order and divided by s*s.
+int oracle_render_sampled(const rtk_scene* scene, const rtk_camera* camera, uint32_t s, uint32_t x0, uint32_t y0,
+                          uint32_t x1, uint32_t y1, double* rgb_f64, uint8_t* rgba8, rtk_stats* stats, int threads) {
+  if (!scene || !camera || s == 0 || x1 > camera->width || y1 > camera->height || x0 > x1 || y0 > y1) return -1;
+  rtk_camera fine = *camera;
+  fine.width = camera->width * s;
+  fine.height = camera->height * s;
+  fine.pixel_size = camera->pixel_size / (double)s;
+  const uint32_t w = x1 - x0, h = y1 - y0;
+  std::vector<double> samples((size_t)w * s * h * s * 3);
+  const int rc = oracle_render(scene, &fine, x0 * s, y0 * s, x1 * s, y1 * s, samples.data(), nullptr, stats, threads);
+  if (rc != 0) return rc;
+  const size_t row = (size_t)w * s * 3;
+  for (uint32_t y = 0; y < h; ++y)
+    for (uint32_t x = 0; x < w; ++x) {
+      double sum[3] = {0.0, 0.0, 0.0};
+      for (uint32_t j = 0; j < s; ++j)
+        for (uint32_t i = 0; i < s; ++i)
+          for (int c = 0; c < 3; ++c)
+            sum[c] += (double)(float)samples[((size_t)y * s + j) * row + ((size_t)x * s + i) * 3 + (size_t)c];
+      const size_t p = (size_t)x + (size_t)y * w;
+      for (int c = 0; c < 3; ++c) {
+        const double mean = sum[c] / (double)(s * s);
+        if (rgb_f64) rgb_f64[3 * p + (size_t)c] = mean;
+        if (rgba8) rgba8[4 * p + (size_t)c] = cast_u8(mean * 255.0);
+      }
+      if (rgba8) rgba8[4 * p + 3] = 255;
+    }
+  return 0;
+}
+
 }  // extern "C"

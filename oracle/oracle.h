@@ -101,6 +101,12 @@ void oracle_trace(const rtk_scene* scene, const double origin[4], const double d
 int oracle_render(const rtk_scene* scene, const rtk_camera* camera, uint32_t x0, uint32_t y0, uint32_t x1,
                   uint32_t y1, double* rgb_f64, uint8_t* rgba8, rtk_stats* stats, int threads);
 
+/* The same with samples_per_axis^2 samples per pixel, as include/rtk.h defines them (the
+ * reference has no counterpart): rgb_f64 receives the f64 mean of the samples' FP32 colours. */
+int oracle_render_sampled(const rtk_scene* scene, const rtk_camera* camera, uint32_t samples_per_axis, uint32_t x0,
+                          uint32_t y0, uint32_t x1, uint32_t y1, double* rgb_f64, uint8_t* rgba8, rtk_stats* stats,
+                          int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,10 @@ def lib():
         L.oracle_render.argtypes = [
             P(abi.rtk_scene), P(abi.rtk_camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
             C.c_void_p, C.c_void_p, P(abi.rtk_stats), C.c_int]
+        L.oracle_render_sampled.restype = C.c_int
+        L.oracle_render_sampled.argtypes = [
+            P(abi.rtk_scene), P(abi.rtk_camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+            C.c_void_p, C.c_void_p, P(abi.rtk_stats), C.c_int]
         _lib = L
     return _lib
 
@@ -248,20 +252,22 @@ def trace(scene, origin, direction):
     return tuple(out)
 
 
-def render(scene, camera, rect=None, threads=1, want_rgb=True, want_rgba8=True):
+def render(scene, camera, rect=None, threads=1, want_rgb=True, want_rgba8=True, samples_per_axis=1):
     """Renders [x0,x1) x [y0,y1) (default: the whole frame).
-    Returns (rgb float64 [h,w,3] or None, rgba8 uint8 [h,w,4] or None, rtk_stats)."""
+    Returns (rgb float64 [h,w,3] or None, rgba8 uint8 [h,w,4] or None, rtk_stats).
+    samples_per_axis > 1: the mean of that many squared samples per pixel (no counterpart in the reference)."""
     s, c = scene.to_abi(), camera.to_abi()
     x0, y0, x1, y1 = rect if rect is not None else (0, 0, camera.width, camera.height)
     w, h = x1 - x0, y1 - y0
     rgb = np.zeros((h, w, 3), dtype=np.float64) if want_rgb else None
     rgba = np.zeros((h, w, 4), dtype=np.uint8) if want_rgba8 else None
     stats = abi.rtk_stats()
-    rc = lib().oracle_render(
-        C.byref(s), C.byref(c), x0, y0, x1, y1,
-        rgb.ctypes.data_as(C.c_void_p) if want_rgb else None,
-        rgba.ctypes.data_as(C.c_void_p) if want_rgba8 else None,
-        C.byref(stats), threads)
+    out = (rgb.ctypes.data_as(C.c_void_p) if want_rgb else None,
+           rgba.ctypes.data_as(C.c_void_p) if want_rgba8 else None, C.byref(stats), threads)
+    if samples_per_axis == 1:
+        rc = lib().oracle_render(C.byref(s), C.byref(c), x0, y0, x1, y1, *out)
+    else:
+        rc = lib().oracle_render_sampled(C.byref(s), C.byref(c), samples_per_axis, x0, y0, x1, y1, *out)
     if rc == -2:
         raise ZeroDivisionError("Failed to invert camera transform")
     if rc != 0:

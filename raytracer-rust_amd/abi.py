@@ -25,6 +25,7 @@ RTK_TEX_STRIPED = 4
 RTK_REFERENCE_MAX_DEPTH = 5
 RTK_MAX_DEPTH_LIMIT = 8
 RTK_TIMING_HISTORY = 64
+RTK_MAX_SAMPLES_PER_AXIS = 16
 RTK_TILE_W = 32
 RTK_TILE_H = 8
 
@@ -123,6 +124,20 @@ SYMBOLS = {
     "rtk_render": (
         C.c_int,
         [C.c_void_p, C.POINTER(rtk_scene), C.POINTER(rtk_camera), C.c_void_p, C.c_void_p, C.POINTER(rtk_stats)],
+    ),
+    "rtk_camera_supersample": (C.c_int, [C.POINTER(rtk_camera), C.c_uint32, C.POINTER(rtk_camera)]),
+    "rtk_render_device_sampled": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.POINTER(rtk_camera), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "rtk_render_sampled": (
+        C.c_int,
+        [C.c_void_p, C.POINTER(rtk_scene), C.POINTER(rtk_camera), C.c_uint32, C.c_void_p, C.c_void_p,
+         C.POINTER(rtk_stats)],
+    ),
+    "rtk_resolve": (
+        C.c_int,
+        [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "rtk_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "rtk_untile": (

@@ -176,6 +176,9 @@ struct rtk_context {
   // intermediate records of the three-kernel path (grown on demand, kept for the next frame)
   rtk::OpaqueBuffers opaque{};
   size_t cap_opaque = 0;
+  // sample frame of rtk_render_device_sampled (grown on demand)
+  float* d_samples = nullptr;
+  size_t cap_samples = 0;  // in samples
 };
 
 extern "C" {
@@ -289,6 +292,7 @@ void rtk_destroy(rtk_context* ctx) {
   if (ctx->opaque.hit_obj) (void)hipFree(ctx->opaque.hit_obj);
   if (ctx->opaque.hit_t) (void)hipFree(ctx->opaque.hit_t);
   if (ctx->opaque.shadow) (void)hipFree(ctx->opaque.shadow);
+  if (ctx->d_samples) (void)hipFree(ctx->d_samples);
   for (int i = 0; i < RTK_TIMING_HISTORY; ++i) {
     if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
     if (ctx->ev_rays[i]) (void)hipEventDestroy(ctx->ev_rays[i]);
@@ -627,8 +631,17 @@ static int make_dev_camera(const rtk_camera* camera, rtk::DevCamera& c) {
   return RTK_OK;
 }
 
-int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, const rtk_tiling* tiling,
-                      float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream) {
+// What follows the render kernels inside the timed region of a sampled call: the sample frame
+// d_rgb_f32 of the (supersampled) camera is averaged into the caller's frame.
+struct ResolveStep {
+  uint32_t s = 1;  // samples per axis; 1 = nothing to do
+  uint32_t width = 0, height = 0;
+  float* d_rgb = nullptr;
+  uint8_t* d_rgba8 = nullptr;
+};
+
+static int render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, const rtk_tiling* tiling,
+                         float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream, const ResolveStep& resolve) {
   if (!ctx || !scene || !camera) return fail(RTK_ERR_INVALID, "rtk_render_device: null argument");
   rtk::DevCamera cam;
   int rc = make_dev_camera(camera, cam);
@@ -677,9 +690,65 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
                                       ctx->opaque, ctx->d_counters, ctx->ev_rays[slot]));
   else
     RTK_HIP(rtk::launch_render(st, scene->dev, cam, scene->d_prim, scene->d_prim_cluster, t, ctx->d_counters));
+  if (resolve.s > 1)
+    RTK_HIP(rtk::launch_resolve(st, resolve.width, resolve.height, resolve.s, d_rgb_f32, resolve.d_rgb, resolve.d_rgba8));
   RTK_HIP(hipEventRecord(ctx->ev_stop[slot], st));
   ctx->last_stream = st;
   ++ctx->n_timed;
+  return RTK_OK;
+}
+
+int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, const rtk_tiling* tiling,
+                      float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream) {
+  return render_device(ctx, scene, camera, tiling, d_rgb_f32, d_rgba8, hip_stream, ResolveStep{});
+}
+
+int rtk_camera_supersample(const rtk_camera* camera, uint32_t s, rtk_camera* out) {
+  if (!camera || !out) return fail(RTK_ERR_INVALID, "rtk_camera_supersample: null argument");
+  if (s == 0 || s > RTK_MAX_SAMPLES_PER_AXIS)
+    return fail(RTK_ERR_INVALID, "rtk_camera_supersample: samples_per_axis must be 1.." + std::to_string(RTK_MAX_SAMPLES_PER_AXIS));
+  if ((uint64_t)camera->width * s > 0xffffffffull || (uint64_t)camera->height * s > 0xffffffffull)
+    return fail(RTK_ERR_UNSUPPORTED, "rtk_camera_supersample: sample frame wider or taller than 2^32 - 1");
+  rtk_camera c = *camera;
+  c.width = camera->width * s;
+  c.height = camera->height * s;
+  c.pixel_size = camera->pixel_size / (double)s;
+  *out = c;
+  return RTK_OK;
+}
+
+int rtk_render_device_sampled(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, uint32_t s,
+                              float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream) {
+  if (!ctx || !scene || !camera) return fail(RTK_ERR_INVALID, "rtk_render_device_sampled: null argument");
+  rtk_camera fine;
+  int rc = rtk_camera_supersample(camera, s, &fine);
+  if (rc != RTK_OK) return rc;
+  if (s == 1) return render_device(ctx, scene, camera, nullptr, d_rgb_f32, d_rgba8, hip_stream, ResolveStep{});
+  RTK_HIP(hipSetDevice(ctx->device));
+  const size_t samples = (size_t)fine.width * fine.height;
+  if (samples > ctx->cap_samples) {
+    // the buffer may still be read by an earlier call on another stream
+    RTK_HIP(hipDeviceSynchronize());
+    if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+    ctx->d_samples = nullptr;
+    ctx->cap_samples = 0;
+    RTK_HIP(hipMalloc((void**)&ctx->d_samples, samples * 3 * sizeof(float)));
+    ctx->cap_samples = samples;
+  }
+  ResolveStep step;
+  step.s = s, step.width = camera->width, step.height = camera->height;
+  step.d_rgb = d_rgb_f32, step.d_rgba8 = d_rgba8;
+  return render_device(ctx, scene, &fine, nullptr, ctx->d_samples, nullptr, hip_stream, step);
+}
+
+int rtk_resolve(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t s, const float* d_samples_rgb_f32,
+                float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream) {
+  if (!ctx || !d_samples_rgb_f32 || width == 0 || height == 0) return fail(RTK_ERR_INVALID, "rtk_resolve: bad argument");
+  if (s == 0 || s > RTK_MAX_SAMPLES_PER_AXIS)
+    return fail(RTK_ERR_INVALID, "rtk_resolve: samples_per_axis must be 1.." + std::to_string(RTK_MAX_SAMPLES_PER_AXIS));
+  RTK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  RTK_HIP(rtk::launch_resolve(st, width, height, s, d_samples_rgb_f32, d_rgb_f32, d_rgba8));
   return RTK_OK;
 }
 
@@ -734,7 +803,14 @@ int rtk_get_timing_history(rtk_context* ctx, uint32_t capacity, double* kernel_m
 
 int rtk_render(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camera, float* rgb_f32_out, uint8_t* rgba8_out,
                rtk_stats* stats) {
+  return rtk_render_sampled(ctx, scene, camera, 1, rgb_f32_out, rgba8_out, stats);
+}
+
+int rtk_render_sampled(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camera, uint32_t samples_per_axis,
+                       float* rgb_f32_out, uint8_t* rgba8_out, rtk_stats* stats) {
   if (!ctx || !scene || !camera) return fail(RTK_ERR_INVALID, "rtk_render: null argument");
+  if (samples_per_axis == 0 || samples_per_axis > RTK_MAX_SAMPLES_PER_AXIS)
+    return fail(RTK_ERR_INVALID, "rtk_render_sampled: samples_per_axis must be 1.." + std::to_string(RTK_MAX_SAMPLES_PER_AXIS));
   rtk_scene_handle* h = nullptr;
   int rc = rtk_scene_upload(ctx, scene, &h);
   if (rc != RTK_OK) return rc;
@@ -753,8 +829,8 @@ int rtk_render(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camer
     }
     ctx->cap_pixels = pixels;
   }
-  rc = rtk_render_device(ctx, h, camera, nullptr, rgb_f32_out ? ctx->d_rgb : nullptr, rgba8_out ? ctx->d_rgba8 : nullptr,
-                         nullptr);
+  rc = rtk_render_device_sampled(ctx, h, camera, samples_per_axis, rgb_f32_out ? ctx->d_rgb : nullptr,
+                                 rgba8_out ? ctx->d_rgba8 : nullptr, nullptr);
   hipError_t e = hipSuccess;
   if (rc == RTK_OK && rgb_f32_out)
     e = hipMemcpyAsync(rgb_f32_out, ctx->d_rgb, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);

@@ -34,5 +34,10 @@ hipError_t launch_trace_rays(hipStream_t st, const DevScene& S, const double* or
 hipError_t launch_untile(hipStream_t st, uint32_t width, uint32_t height, uint32_t world, uint64_t rgb_stride_floats,
                          uint64_t px_stride_pixels, const float* rgb_c, float* rgb_f, const uint8_t* px_c, uint8_t* px_f);
 
+// s x s supersampled FP32 frame (s*width x s*height samples, row-major) -> width x height
+// frame: per-pixel mean, FP32 and RGBA8 (either output may be null).
+hipError_t launch_resolve(hipStream_t st, uint32_t width, uint32_t height, uint32_t s, const float* samples, float* rgb,
+                          uint8_t* rgba8);
+
 }  // namespace rtk
 #endif

@@ -335,6 +335,37 @@ __global__ void __launch_bounds__(kBlock) untile_kernel(uint32_t width, uint32_t
   }
 }
 
+// Box filter of a supersampled frame: pixel (x, y) is the mean of the s x s samples
+// (s x + i, s y + j) of a frame of s*width x s*height FP32 RGB samples, summed in f64 in
+// row-major order (j outer, i inner), divided by s*s, then narrowed to FP32 and cast to 8 bits
+// as a rendered colour is (src/graphics.rs:59-74).  One thread per pixel.
+__global__ void __launch_bounds__(kBlock) resolve_kernel(uint32_t width, uint32_t height, uint32_t s,
+                                                         const float* __restrict__ samples, float* __restrict__ rgb,
+                                                         uint32_t* __restrict__ rgba8) {
+  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= (uint64_t)width * height) return;
+  const uint32_t x = (uint32_t)(p % width), y = (uint32_t)(p / width);
+  const size_t row = (size_t)width * s * 3u;
+  const float* src = samples + (size_t)y * s * row + (size_t)x * s * 3u;
+  double r = 0.0, g = 0.0, b = 0.0;
+  for (uint32_t j = 0; j < s; ++j) {
+    const float* line = src + (size_t)j * row;
+    for (uint32_t i = 0; i < s; ++i) {
+      r += (double)line[3u * i + 0u];
+      g += (double)line[3u * i + 1u];
+      b += (double)line[3u * i + 2u];
+    }
+  }
+  const double n = (double)(s * s);
+  r /= n, g /= n, b /= n;
+  if (rgb) {
+    rgb[p * 3u + 0u] = (float)r;
+    rgb[p * 3u + 1u] = (float)g;
+    rgb[p * 3u + 2u] = (float)b;
+  }
+  if (rgba8) rgba8[p] = cast_u8(r) | (cast_u8(g) << 8) | (cast_u8(b) << 16) | 0xff000000u;
+}
+
 // ------------------------------------------------------------------------------------
 // launch wrappers (called from rtk_api.hip)
 
@@ -408,6 +439,15 @@ hipError_t launch_untile(hipStream_t st, uint32_t width, uint32_t height, uint32
   hipLaunchKernelGGL(untile_kernel, dim3(n_tiles), dim3(kBlock), 0, st, width, height, tiles_x, n_tiles, world,
                      rgb_stride_floats, px_stride_pixels, rgb_c, rgb_f, reinterpret_cast<const uint32_t*>(px_c),
                      reinterpret_cast<uint32_t*>(px_f));
+  return hipGetLastError();
+}
+
+hipError_t launch_resolve(hipStream_t st, uint32_t width, uint32_t height, uint32_t s, const float* samples, float* rgb,
+                          uint8_t* rgba8) {
+  const uint64_t pixels = (uint64_t)width * height;
+  if (pixels == 0) return hipSuccess;
+  hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((pixels + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, width, height, s,
+                     samples, rgb, reinterpret_cast<uint32_t*>(rgba8));
   return hipGetLastError();
 }
 

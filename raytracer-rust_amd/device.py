@@ -133,6 +133,37 @@ class Device:
             C.c_void_p(stream)))
         return rgb, rgba
 
+    def render_device_sampled(self, handle, camera, samples_per_axis, want_rgb=True, want_rgba8=True):
+        """render_device with samples_per_axis squared samples per pixel (whole frame; the
+        reference has one sample per pixel, src/scene/cameras.rs:53-54)."""
+        torch = self.torch
+        cam = camera.to_abi() if hasattr(camera, "to_abi") else camera
+        rgb = torch.empty((cam.height, cam.width, 3), dtype=torch.float32, device=self.tdev) if want_rgb else None
+        rgba = torch.empty((cam.height, cam.width, 4), dtype=torch.uint8, device=self.tdev) if want_rgba8 else None
+        stream = torch.cuda.current_stream(self.tdev).cuda_stream
+        _check(library().rtk_render_device_sampled(
+            self.ctx, handle.handle, C.byref(cam), int(samples_per_axis),
+            C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
+            C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
+            C.c_void_p(stream)))
+        return rgb, rgba
+
+    def resolve(self, samples, samples_per_axis):
+        """Averages a [s*H, s*W, 3] float32 sample frame on this device into ([H, W, 3] float32, [H, W, 4] uint8)."""
+        torch = self.torch
+        s = int(samples_per_axis)
+        if samples.dim() != 3 or samples.shape[2] != 3 or samples.dtype != torch.float32 or not samples.is_contiguous():
+            raise ValueError("samples must be a contiguous [s*H, s*W, 3] float32 tensor")
+        if s < 1 or samples.shape[0] % s or samples.shape[1] % s:
+            raise ValueError("sample frame is not a multiple of samples_per_axis")
+        h, w = samples.shape[0] // s, samples.shape[1] // s
+        rgb = torch.empty((h, w, 3), dtype=torch.float32, device=self.tdev)
+        rgba = torch.empty((h, w, 4), dtype=torch.uint8, device=self.tdev)
+        stream = torch.cuda.current_stream(self.tdev).cuda_stream
+        _check(library().rtk_resolve(self.ctx, w, h, s, C.c_void_p(samples.data_ptr()), C.c_void_p(rgb.data_ptr()),
+                                     C.c_void_p(rgba.data_ptr()), C.c_void_p(stream)))
+        return rgb, rgba
+
     def stats(self):
         st = abi.rtk_stats()
         _check(library().rtk_get_stats(self.ctx, C.byref(st)))
@@ -147,15 +178,15 @@ class Device:
             _check(got)
         return list(k[:got]), list(r[:got])
 
-    def render(self, scene, camera):
+    def render(self, scene, camera, samples_per_axis=1):
         """`Camera::render` through the host-buffer entry point; returns a Canvas."""
         s = scene.to_abi() if hasattr(scene, "to_abi") else scene
         cam = camera.to_abi() if hasattr(camera, "to_abi") else camera
         rgb = np.empty((cam.height, cam.width, 3), dtype=np.float32)
         rgba = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
         st = abi.rtk_stats()
-        _check(library().rtk_render(self.ctx, C.byref(s), C.byref(cam), rgb.ctypes.data_as(C.c_void_p),
-                                    rgba.ctypes.data_as(C.c_void_p), C.byref(st)))
+        _check(library().rtk_render_sampled(self.ctx, C.byref(s), C.byref(cam), int(samples_per_axis),
+                                            rgb.ctypes.data_as(C.c_void_p), rgba.ctypes.data_as(C.c_void_p), C.byref(st)))
         return Canvas(cam.width, cam.height, rgb, rgba, st)
 
     def trace(self, handle, origins, directions):

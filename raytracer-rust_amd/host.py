@@ -361,9 +361,22 @@ class Camera:
         c.transform[:] = self.transform.e
         return c
 
-    def render(self, scene, device=None):
-        """`Camera::render(&self, scene) -> Canvas` (cameras.rs:72-85) on the device."""
+    def supersampled(self, samples_per_axis):
+        """The camera whose pixels are this camera's samples: the same view at samples_per_axis
+        times the resolution (no counterpart in the reference, which samples pixel centres only)."""
+        s = int(samples_per_axis)
+        if s < 1 or s > abi.RTK_MAX_SAMPLES_PER_AXIS:
+            raise ValueError(f"samples_per_axis must be 1..{abi.RTK_MAX_SAMPLES_PER_AXIS}")
+        c = Camera.__new__(Camera)
+        c.__dict__.update(self.__dict__)
+        c.width, c.height = self.width * s, self.height * s
+        c.pixel_size = self.pixel_size / float(s)
+        return c
+
+    def render(self, scene, device=None, samples_per_axis=1):
+        """`Camera::render(&self, scene) -> Canvas` (cameras.rs:72-85) on the device;
+        samples_per_axis > 1 averages that many squared samples per pixel."""
         from . import device as _device
 
         dev = device if device is not None else _device.default_device()
-        return dev.render(scene, self)
+        return dev.render(scene, self, samples_per_axis)

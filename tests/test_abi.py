@@ -86,3 +86,26 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_camera_supersample(rtk, lib):
+    """The sample camera: same view, s times the resolution, pixel_size / s (no GPU needed)."""
+    cam = rtk.Camera(200, 125, math.pi / 2)
+    cam.transform = rtk.Matrix4x4.look_at(rtk.point(1, 2, -3), rtk.point(0, 0, 0), rtk.vec3(0, 1, 0))
+    src = cam.to_abi()
+    for s in (1, 2, 3, 8, 16):
+        out = rtk.abi.rtk_camera()
+        assert lib.rtk_camera_supersample(C.byref(src), s, C.byref(out)) == 0
+        host = cam.supersampled(s).to_abi()
+        for f in ("width", "height", "half_width", "half_height", "field_of_view", "pixel_size"):
+            assert getattr(out, f) == getattr(host, f), (s, f)
+        assert (out.width, out.height, out.pixel_size) == (200 * s, 125 * s, src.pixel_size / s)
+        assert list(out.transform) == list(src.transform)
+    out = rtk.abi.rtk_camera()
+    for bad in (0, 17):
+        assert lib.rtk_camera_supersample(C.byref(src), bad, C.byref(out)) == rtk.abi.RTK_ERR_INVALID
+        with pytest.raises(ValueError):
+            cam.supersampled(bad)
+    assert lib.rtk_camera_supersample(None, 2, C.byref(out)) == rtk.abi.RTK_ERR_INVALID
+    big = rtk.Camera(1 << 30, 8, 1.0).to_abi()
+    assert lib.rtk_camera_supersample(C.byref(big), 4, C.byref(out)) == rtk.abi.RTK_ERR_UNSUPPORTED

@@ -230,3 +230,16 @@ def test_frames_through_the_rccl_process_group(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, str(script), root, str(port)], capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_sampled_render_rejects_bad_sample_counts(rtk, dev, device_mod):
+    scene, camera = rtk.synthetic.config("C2", 32, 16)
+    h = dev.upload(scene)
+    for bad in (0, 17):
+        with pytest.raises(device_mod.RtkError) as e:
+            dev.render_device_sampled(h, camera, bad)
+        assert e.value.code == rtk.abi.RTK_ERR_INVALID
+        with pytest.raises(device_mod.RtkError) as e:
+            dev.render(scene, camera, samples_per_axis=bad)
+        assert e.value.code == rtk.abi.RTK_ERR_INVALID
+    h.release()

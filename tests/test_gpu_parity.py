@@ -441,3 +441,84 @@ def test_randomised_scenes(rtk, dev, oracle):
     for seed in range(2000, 2120):
         scene, camera, what = random_scene(rtk, np.random.default_rng(seed))
         check_against_oracle(dev, oracle, scene, camera, f"seed {seed}: {what}")
+
+
+# ---------------------------------------------------------------- more than one sample per pixel
+# The reference has one sample per pixel (src/scene/cameras.rs:53-54): the averaging step is
+# checked against the oracle's restatement of this library's own definition (parity unpinned);
+# the samples themselves are pixels of the reference's camera model and are pinned as above.
+def check_sampled(dev, oracle, scene, camera, s, what):
+    canvas = dev.render(scene, camera, samples_per_axis=s)
+    rgb, rgba, ost = oracle.render(scene, camera, threads=16, samples_per_axis=s)
+    assert counts(canvas.stats) == counts(ost), what
+    assert canvas.stats.rays_primary == camera.width * camera.height * s * s
+    max_rel, _, _, not_equal = assert_parity(canvas.rgb, canvas.rgba8, rgb, rgba, what)
+    assert not_equal == 0, f"{what}: {not_equal} pixels differ after the 8-bit cast"
+    # FP32 samples equal the oracle's, so the f64 mean of them does, and so does its narrowing
+    assert (canvas.rgb == rgb.astype(np.float32)).all(), f"{what}: max relative error {max_rel:.3e}"
+    assert (canvas.rgba8[..., 3] == 255).all()
+    return canvas
+
+
+@pytest.mark.parametrize("name,w,h,s", [("C2", 320, 180, 2), ("C2", 213, 120, 3), ("C2", 160, 90, 4), ("C3", 192, 108, 2),
+                                        ("C2g", 160, 90, 2), ("C2", 37, 19, 8), ("C2", 8, 5, 16)])
+def test_sampled_render_matches_the_oracle(rtk, dev, oracle, name, w, h, s):
+    scene, camera = rtk.synthetic.config(name, w, h)
+    check_sampled(dev, oracle, scene, camera, s, f"{name} {w}x{h} s={s}")
+
+
+def test_sampled_bundled_scene(rtk, dev, oracle, golden_dir):
+    scene = rtk.PackedScene.from_yaml_file(os.path.join(golden_dir, "test01.yaml")).build()
+    check_sampled(dev, oracle, scene, rtk.Camera(240, 135, rtk.PI / 3.0), 2, "C1 240x135 s=2")
+
+
+def test_one_sample_per_axis_is_the_plain_render(rtk, dev):
+    scene, camera = rtk.synthetic.config("C2", 640, 360)
+    a = dev.render(scene, camera)
+    b = dev.render(scene, camera, samples_per_axis=1)
+    assert (a.rgb == b.rgb).all() and (a.rgba8 == b.rgba8).all() and counts(a.stats) == counts(b.stats)
+
+
+def test_sampled_device_render_and_resolve_alone(rtk, dev):
+    """Device outputs: the sampled call equals rendering the finer camera and averaging it with
+    rtk_resolve; a smaller frame after a larger one reuses the context's sample buffer."""
+    import torch
+
+    scene, _ = rtk.synthetic.config("C2", 8, 8)
+    h = dev.upload(scene)
+    for (w, hh, s) in [(256, 144, 3), (128, 72, 2)]:
+        _, camera = rtk.synthetic.config("C2", w, hh)
+        rgb, rgba = dev.render_device_sampled(h, camera, s)
+        fine, _ = dev.render_device(h, camera.supersampled(s), want_rgba8=False)
+        rgb2, rgba2 = dev.resolve(fine, s)
+        torch.cuda.synchronize()
+        assert torch.equal(rgb, rgb2) and torch.equal(rgba, rgba2)
+        f = fine.cpu().numpy().astype(np.float64).reshape(hh, s, w, s, 3)
+        acc = np.zeros((hh, w, 3))
+        for j in range(s):
+            for i in range(s):
+                acc = acc + f[:, j, :, i, :]
+        mean = acc / float(s * s)
+        assert (rgb.cpu().numpy() == mean.astype(np.float32)).all()
+        v = mean * 255.0
+        expect8 = np.where(v > 0.0, np.minimum(v, 255.0), 0.0).astype(np.uint8)
+        assert (rgba.cpu().numpy()[..., :3] == expect8).all()
+    h.release()
+
+
+def test_resolve_of_special_values(rtk, dev):
+    """Saturation, negative and NaN samples go through the 8-bit cast like a single colour does."""
+    import torch
+
+    s = 2
+    samples = torch.zeros((2 * s, 3 * s, 3), dtype=torch.float32, device=dev.tdev)
+    samples[0:2, 0:2] = 2.0                     # pixel (0,0): saturates
+    samples[0:2, 2:4] = -1.0                    # pixel (1,0): negative -> 0
+    samples[0:2, 4:6] = float("nan")            # pixel (2,0): NaN -> 0
+    samples[2:4, 0:2, 0] = torch.tensor([[0.25, 0.5], [0.75, 1.0]], device=dev.tdev)  # mean 0.625 -> 159
+    rgb, rgba = dev.resolve(samples, s)
+    torch.cuda.synchronize()
+    rgba = rgba.cpu().numpy()
+    assert tuple(rgba[0, 0]) == (255, 255, 255, 255) and tuple(rgba[0, 1]) == (0, 0, 0, 255)
+    assert tuple(rgba[0, 2]) == (0, 0, 0, 255) and tuple(rgba[1, 0]) == (159, 0, 0, 255)
+    assert float(rgb[1, 0, 0]) == 0.625 and bool(torch.isnan(rgb[0, 2]).all())

@@ -195,3 +195,26 @@ def test_command_line_renderer_options_and_errors(host_bin, golden_dir, tmp_path
     assert Image.open(out).size == (200, 120)
     r = subprocess.run([os.path.join(host_bin, "rtk_render"), str(tmp_path / "absent.yaml"), str(out)], capture_output=True, text=True)
     assert r.returncode == 1 and "cannot open" in r.stderr
+
+
+@pytest.mark.gpu
+def test_command_line_renderer_with_samples(rtk, host_bin, golden_dir, tmp_path):
+    """`--samples 2`: the PNG holds the Python host's sampled render of the same scene, byte for byte."""
+    import importlib
+
+    from PIL import Image
+
+    out = tmp_path / "aa.png"
+    scene_file = os.path.join(golden_dir, "test01.yaml")
+    r = subprocess.run([os.path.join(host_bin, "rtk_render"), scene_file, str(out), "--width", "320", "--height", "180",
+                        "--samples", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert f"rays: {320 * 180 * 4} primary" in r.stdout
+    dev = importlib.import_module("raytracer-rust_amd.device").Device(0)
+    canvas = rtk.Camera(320, 180, rtk.PI / 3.0).render(rtk.PackedScene.from_yaml_file(scene_file).build(), dev,
+                                                      samples_per_axis=2)
+    dev.close()
+    assert (np.asarray(Image.open(out)) == canvas.rgba8).all()
+    r = subprocess.run([os.path.join(host_bin, "rtk_render"), scene_file, str(out), "--samples", "0"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "samples_per_axis" in r.stderr

@@ -19,6 +19,22 @@ for name in names:
     elif name == "C3w1":           # C3 with w = 1 lights: the two-kernel opaque path
         scene, camera = rtk.synthetic.config("C3")
         scene.lights = [rtk.PointLight(rtk.point(*l.position[:3]), l.intensity) for l in scene.lights]
+    elif name in ("C4s2", "C4s4"):  # C4 at 4K / 1080p with 2x2 / 4x4 samples per pixel: the averaging kernel
+        sp = int(name[-1])
+        scene, camera = rtk.synthetic.config("C4", 3840 * 2 // sp, 2160 * 2 // sp)
+        h = dev.upload(scene)
+        best = None
+        for _ in range(6):
+            dev.render_device_sampled(h, camera, sp)
+            st = dev.stats()
+            if best is None or st.kernel_ms < best.kernel_ms:
+                best = st
+        px = camera.width * camera.height
+        ms = best.kernel_ms - best.rays_ms
+        print(f"{name}: {best.kernel_ms:8.3f} ms ({camera.width}x{camera.height}, {sp * sp} samples per pixel), of which averaging "
+              f"{ms:.3f} ms = {px * (12 * sp * sp + 16) / (ms * 1e-3) / 1e9:.0f} GB/s", flush=True)
+        h.release()
+        continue
     elif name == "C5s":
         scene, camera = rtk.synthetic.config("C5", 4096, 4096)
     else:

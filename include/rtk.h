@@ -198,11 +198,24 @@ int rtk_render(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camer
 #define RTK_MAX_SAMPLES_PER_AXIS 16
 int rtk_camera_supersample(const rtk_camera* camera, uint32_t samples_per_axis, rtk_camera* out);
 
-/* rtk_render_device with s*s samples per pixel (whole frame, row-major device outputs; the
- * sample frame lives in a buffer of the context that grows on demand).  Ray counts and
- * kernel times of the call cover all samples and the averaging kernel. */
+/* rtk_render_device with s*s samples per pixel.  The sample frame lives in a buffer of the
+ * context that grows on demand, so sampled calls of one context must not overlap on
+ * different streams.  Ray counts and kernel times of the call cover all samples and the
+ * averaging kernel.  tiling: NULL or world == 1 writes row-major frames.  With world > 1
+ * (samples_per_axis 1, 2, 4 or 8 only) the rank renders the 32x8 tiles t % world == rank of
+ * the SAMPLE frame and averages each into a (32/s) x (8/s) tile of pixels; the outputs hold
+ * rtk_compact_pixels_sampled() pixels, tile after tile, row-major inside a tile;
+ * rtk_untile_sampled() rebuilds the frame from the gathered buffers. */
 int rtk_render_device_sampled(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera,
-                              uint32_t samples_per_axis, float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream);
+                              uint32_t samples_per_axis, const rtk_tiling* tiling, float* d_rgb_f32,
+                              uint8_t* d_rgba8, void* hip_stream);
+uint64_t rtk_compact_pixels_sampled(uint32_t width, uint32_t height, uint32_t samples_per_axis, uint32_t rank,
+                                    uint32_t world);
+/* rtk_untile_strided for the buffers of sampled, tiled renders (width, height: the frame's). */
+int rtk_untile_sampled(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t samples_per_axis, uint32_t world,
+                       uint64_t rgb_rank_stride_bytes, uint64_t rgba8_rank_stride_bytes,
+                       const float* d_rgb_f32_compact, float* d_rgb_f32_frame,
+                       const uint8_t* d_rgba8_compact, uint8_t* d_rgba8_frame, void* hip_stream);
 
 /* rtk_render with s*s samples per pixel (host outputs). */
 int rtk_render_sampled(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camera, uint32_t samples_per_axis,

@@ -128,7 +128,14 @@ SYMBOLS = {
     "rtk_camera_supersample": (C.c_int, [C.POINTER(rtk_camera), C.c_uint32, C.POINTER(rtk_camera)]),
     "rtk_render_device_sampled": (
         C.c_int,
-        [C.c_void_p, C.c_void_p, C.POINTER(rtk_camera), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p],
+        [C.c_void_p, C.c_void_p, C.POINTER(rtk_camera), C.c_uint32, C.POINTER(rtk_tiling), C.c_void_p, C.c_void_p,
+         C.c_void_p],
+    ),
+    "rtk_compact_pixels_sampled": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rtk_untile_sampled": (
+        C.c_int,
+        [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
+         C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "rtk_render_sampled": (
         C.c_int,

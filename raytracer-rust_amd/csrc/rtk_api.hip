@@ -638,6 +638,7 @@ struct ResolveStep {
   uint32_t width = 0, height = 0;
   float* d_rgb = nullptr;
   uint8_t* d_rgba8 = nullptr;
+  bool tiles = false;  // the sample frame is a rank's compact tile buffer
 };
 
 static int render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, const rtk_tiling* tiling,
@@ -690,7 +691,9 @@ static int render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_ca
                                       ctx->opaque, ctx->d_counters, ctx->ev_rays[slot]));
   else
     RTK_HIP(rtk::launch_render(st, scene->dev, cam, scene->d_prim, scene->d_prim_cluster, t, ctx->d_counters));
-  if (resolve.s > 1)
+  if (resolve.s > 1 && resolve.tiles)
+    RTK_HIP(rtk::launch_resolve_tiles(st, t.n_local_tiles, resolve.s, d_rgb_f32, resolve.d_rgb, resolve.d_rgba8));
+  else if (resolve.s > 1)
     RTK_HIP(rtk::launch_resolve(st, resolve.width, resolve.height, resolve.s, d_rgb_f32, resolve.d_rgb, resolve.d_rgba8));
   RTK_HIP(hipEventRecord(ctx->ev_stop[slot], st));
   ctx->last_stream = st;
@@ -717,15 +720,29 @@ int rtk_camera_supersample(const rtk_camera* camera, uint32_t s, rtk_camera* out
   return RTK_OK;
 }
 
+uint64_t rtk_compact_pixels_sampled(uint32_t width, uint32_t height, uint32_t s, uint32_t rank, uint32_t world) {
+  if (s == 0 || s > RTK_MAX_SAMPLES_PER_AXIS || (uint64_t)width * s > 0xffffffffull || (uint64_t)height * s > 0xffffffffull)
+    return 0;
+  if (world <= 1) return rank == 0 && world == 1 ? (uint64_t)width * height : 0;
+  if (8u % s != 0) return 0;
+  return rtk_tiles_for_rank(width * s, height * s, rank, world) * (uint64_t)(RTK_TILE_W * RTK_TILE_H / (s * s));
+}
+
 int rtk_render_device_sampled(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, uint32_t s,
-                              float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream) {
+                              const rtk_tiling* tiling, float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream) {
   if (!ctx || !scene || !camera) return fail(RTK_ERR_INVALID, "rtk_render_device_sampled: null argument");
   rtk_camera fine;
   int rc = rtk_camera_supersample(camera, s, &fine);
   if (rc != RTK_OK) return rc;
-  if (s == 1) return render_device(ctx, scene, camera, nullptr, d_rgb_f32, d_rgba8, hip_stream, ResolveStep{});
+  if (s == 1) return render_device(ctx, scene, camera, tiling, d_rgb_f32, d_rgba8, hip_stream, ResolveStep{});
+  rtk_tiling tl = {0u, 1u};
+  if (tiling) tl = *tiling;
+  if (tl.world == 0 || tl.rank >= tl.world) return fail(RTK_ERR_INVALID, "rtk_render_device_sampled: bad tiling (rank >= world)");
+  if (tl.world > 1 && 8u % s != 0)
+    return fail(RTK_ERR_UNSUPPORTED, "rtk_render_device_sampled: with world > 1 samples_per_axis must be 1, 2, 4 or 8");
   RTK_HIP(hipSetDevice(ctx->device));
-  const size_t samples = (size_t)fine.width * fine.height;
+  const size_t samples = tl.world > 1 ? (size_t)rtk_compact_pixels(fine.width, fine.height, tl.rank, tl.world)
+                                      : (size_t)fine.width * fine.height;
   if (samples > ctx->cap_samples) {
     // the buffer may still be read by an earlier call on another stream
     RTK_HIP(hipDeviceSynchronize());
@@ -738,7 +755,8 @@ int rtk_render_device_sampled(rtk_context* ctx, rtk_scene_handle* scene, const r
   ResolveStep step;
   step.s = s, step.width = camera->width, step.height = camera->height;
   step.d_rgb = d_rgb_f32, step.d_rgba8 = d_rgba8;
-  return render_device(ctx, scene, &fine, nullptr, ctx->d_samples, nullptr, hip_stream, step);
+  step.tiles = tl.world > 1;
+  return render_device(ctx, scene, &fine, &tl, ctx->d_samples, nullptr, hip_stream, step);
 }
 
 int rtk_resolve(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t s, const float* d_samples_rgb_f32,
@@ -829,7 +847,7 @@ int rtk_render_sampled(rtk_context* ctx, const rtk_scene* scene, const rtk_camer
     }
     ctx->cap_pixels = pixels;
   }
-  rc = rtk_render_device_sampled(ctx, h, camera, samples_per_axis, rgb_f32_out ? ctx->d_rgb : nullptr,
+  rc = rtk_render_device_sampled(ctx, h, camera, samples_per_axis, nullptr, rgb_f32_out ? ctx->d_rgb : nullptr,
                                  rgba8_out ? ctx->d_rgba8 : nullptr, nullptr);
   hipError_t e = hipSuccess;
   if (rc == RTK_OK && rgb_f32_out)
@@ -907,6 +925,33 @@ int rtk_untile_strided(rtk_context* ctx, uint32_t width, uint32_t height, uint32
                        const uint8_t* d_rgba8_compact, uint8_t* d_rgba8_frame, void* hip_stream) {
   return untile_checked(ctx, width, height, world, rgb_rank_stride_bytes, rgba8_rank_stride_bytes, d_rgb_f32_compact,
                         d_rgb_f32_frame, d_rgba8_compact, d_rgba8_frame, hip_stream, "rtk_untile_strided");
+}
+
+int rtk_untile_sampled(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t s, uint32_t world,
+                       uint64_t rgb_rank_stride_bytes, uint64_t rgba8_rank_stride_bytes, const float* d_rgb_f32_compact,
+                       float* d_rgb_f32_frame, const uint8_t* d_rgba8_compact, uint8_t* d_rgba8_frame, void* hip_stream) {
+  const char* who = "rtk_untile_sampled";
+  if (s == 1)
+    return untile_checked(ctx, width, height, world, rgb_rank_stride_bytes, rgba8_rank_stride_bytes, d_rgb_f32_compact,
+                          d_rgb_f32_frame, d_rgba8_compact, d_rgba8_frame, hip_stream, who);
+  if (!ctx || width == 0 || height == 0 || world == 0) return fail(RTK_ERR_INVALID, std::string(who) + ": bad argument");
+  if (s == 0 || s > 8 || 8u % s != 0) return fail(RTK_ERR_UNSUPPORTED, std::string(who) + ": samples_per_axis must be 1, 2, 4 or 8");
+  if ((uint64_t)width * s > 0xffffffffull || (uint64_t)height * s > 0xffffffffull)
+    return fail(RTK_ERR_UNSUPPORTED, std::string(who) + ": sample frame wider or taller than 2^32 - 1");
+  if ((d_rgb_f32_compact == nullptr) != (d_rgb_f32_frame == nullptr) || (d_rgba8_compact == nullptr) != (d_rgba8_frame == nullptr))
+    return fail(RTK_ERR_INVALID, std::string(who) + ": compact and frame pointers must come in pairs");
+  if (rgb_rank_stride_bytes % 4u != 0 || rgba8_rank_stride_bytes % 4u != 0)
+    return fail(RTK_ERR_INVALID, std::string(who) + ": rank strides must be multiples of 4 bytes");
+  const uint64_t largest = rtk_compact_pixels_sampled(width, height, s, 0, world);
+  if (world > 1 && ((d_rgb_f32_compact && rgb_rank_stride_bytes < largest * 12u) ||
+                    (d_rgba8_compact && rgba8_rank_stride_bytes < largest * 4u)))
+    return fail(RTK_ERR_INVALID, std::string(who) + ": rank stride smaller than a rank's compact buffer");
+  if (world == 1) return fail(RTK_ERR_INVALID, std::string(who) + ": a single rank renders row-major frames; nothing to rebuild");
+  RTK_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  RTK_HIP(rtk::launch_untile_sampled(st, width, height, s, world, rgb_rank_stride_bytes / 4u, rgba8_rank_stride_bytes / 4u,
+                                     d_rgb_f32_compact, d_rgb_f32_frame, d_rgba8_compact, d_rgba8_frame));
+  return RTK_OK;
 }
 
 }  // extern "C"

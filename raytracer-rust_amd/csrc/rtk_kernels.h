@@ -39,5 +39,14 @@ hipError_t launch_untile(hipStream_t st, uint32_t width, uint32_t height, uint32
 hipError_t launch_resolve(hipStream_t st, uint32_t width, uint32_t height, uint32_t s, const float* samples, float* rgb,
                           uint8_t* rgba8);
 
+// The same on a rank's compact buffer of n_tiles 32x8 sample tiles (s divides 8): tile k becomes
+// 256 / s^2 pixels, a (32/s) x (8/s) tile in row-major order.
+hipError_t launch_resolve_tiles(hipStream_t st, uint64_t n_tiles, uint32_t s, const float* samples, float* rgb, uint8_t* rgba8);
+
+// launch_untile for buffers made of such (32/s) x (8/s) tiles.
+hipError_t launch_untile_sampled(hipStream_t st, uint32_t width, uint32_t height, uint32_t s, uint32_t world,
+                                 uint64_t rgb_stride_floats, uint64_t px_stride_pixels, const float* rgb_c, float* rgb_f,
+                                 const uint8_t* px_c, uint8_t* px_f);
+
 }  // namespace rtk
 #endif

@@ -366,6 +366,56 @@ __global__ void __launch_bounds__(kBlock) resolve_kernel(uint32_t width, uint32_
   if (rgba8) rgba8[p] = cast_u8(r) | (cast_u8(g) << 8) | (cast_u8(b) << 16) | 0xff000000u;
 }
 
+// The same average on a rank's compact tile buffer (s divides 8): each 32x8 tile of samples
+// becomes a (32/s) x (8/s) tile of pixels, row-major inside the tile, tiles in the same order.
+__global__ void __launch_bounds__(kBlock) resolve_tiles_kernel(uint64_t n_pixels, uint32_t s, const float* __restrict__ samples,
+                                                               float* __restrict__ rgb, uint32_t* __restrict__ rgba8) {
+  const uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= n_pixels) return;
+  const uint32_t tw = 32u / s, per_tile = 256u / (s * s);
+  const uint64_t k = q / per_tile;
+  const uint32_t r = (uint32_t)(q % per_tile), lx = r % tw, ly = r / tw;
+  const float* src = samples + (k * 256u + (uint64_t)(ly * s) * 32u + lx * s) * 3u;
+  double cr = 0.0, cg = 0.0, cb = 0.0;
+  for (uint32_t j = 0; j < s; ++j)
+    for (uint32_t i = 0; i < s; ++i) {
+      const float* e = src + (j * 32u + i) * 3u;
+      cr += (double)e[0];
+      cg += (double)e[1];
+      cb += (double)e[2];
+    }
+  const double n = (double)(s * s);
+  cr /= n, cg /= n, cb /= n;
+  if (rgb) {
+    rgb[q * 3u + 0u] = (float)cr;
+    rgb[q * 3u + 1u] = (float)cg;
+    rgb[q * 3u + 2u] = (float)cb;
+  }
+  if (rgba8) rgba8[q] = cast_u8(cr) | (cast_u8(cg) << 8) | (cast_u8(cb) << 16) | 0xff000000u;
+}
+
+// De-interleave of such buffers: the frame's tiles are (32/s) x (8/s) pixels, numbered like the
+// 32x8 tiles of the sample frame they came from.  One thread per pixel of the frame.
+__global__ void __launch_bounds__(kBlock) untile_sampled_kernel(uint32_t width, uint32_t height, uint32_t s, uint32_t tiles_x,
+                                                                uint32_t world, uint64_t rgb_stride, uint64_t px_stride,
+                                                                const float* __restrict__ rgb_c, float* __restrict__ rgb_f,
+                                                                const uint32_t* __restrict__ px_c, uint32_t* __restrict__ px_f) {
+  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= (uint64_t)width * height) return;
+  const uint32_t x = (uint32_t)(p % width), y = (uint32_t)(p / width);
+  const uint32_t tw = 32u / s, th = 8u / s, per_tile = tw * th;
+  const uint32_t tile = (y / th) * tiles_x + x / tw;
+  const uint32_t rank = tile % world, k = tile / world;
+  const uint64_t q = (uint64_t)k * per_tile + (y % th) * tw + x % tw;
+  if (px_c) px_f[p] = px_c[(uint64_t)rank * px_stride + q];
+  if (rgb_c) {
+    const float* src = rgb_c + (uint64_t)rank * rgb_stride + q * 3u;
+    rgb_f[p * 3u + 0u] = src[0];
+    rgb_f[p * 3u + 1u] = src[1];
+    rgb_f[p * 3u + 2u] = src[2];
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // launch wrappers (called from rtk_api.hip)
 
@@ -448,6 +498,26 @@ hipError_t launch_resolve(hipStream_t st, uint32_t width, uint32_t height, uint3
   if (pixels == 0) return hipSuccess;
   hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((pixels + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, width, height, s,
                      samples, rgb, reinterpret_cast<uint32_t*>(rgba8));
+  return hipGetLastError();
+}
+
+hipError_t launch_resolve_tiles(hipStream_t st, uint64_t n_tiles, uint32_t s, const float* samples, float* rgb, uint8_t* rgba8) {
+  const uint64_t pixels = n_tiles * (256u / (s * s));
+  if (pixels == 0) return hipSuccess;
+  hipLaunchKernelGGL(resolve_tiles_kernel, dim3((unsigned)((pixels + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pixels, s,
+                     samples, rgb, reinterpret_cast<uint32_t*>(rgba8));
+  return hipGetLastError();
+}
+
+hipError_t launch_untile_sampled(hipStream_t st, uint32_t width, uint32_t height, uint32_t s, uint32_t world,
+                                 uint64_t rgb_stride_floats, uint64_t px_stride_pixels, const float* rgb_c, float* rgb_f,
+                                 const uint8_t* px_c, uint8_t* px_f) {
+  const uint64_t pixels = (uint64_t)width * height;
+  if (pixels == 0) return hipSuccess;
+  const uint32_t tiles_x = (uint32_t)(((uint64_t)width * s + 31u) / 32u);
+  hipLaunchKernelGGL(untile_sampled_kernel, dim3((unsigned)((pixels + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, width, height,
+                     s, tiles_x, world, rgb_stride_floats, px_stride_pixels, rgb_c, rgb_f,
+                     reinterpret_cast<const uint32_t*>(px_c), reinterpret_cast<uint32_t*>(px_f));
   return hipGetLastError();
 }
 

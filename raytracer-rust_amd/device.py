@@ -64,6 +64,10 @@ def compact_pixels(width, height, rank, world):
     return int(library().rtk_compact_pixels(width, height, rank, world))
 
 
+def compact_pixels_sampled(width, height, samples_per_axis, rank, world):
+    return int(library().rtk_compact_pixels_sampled(width, height, samples_per_axis, rank, world))
+
+
 class SceneHandle:
     def __init__(self, device, handle, scene_abi):
         self.device, self.handle, self._keep = device, handle, scene_abi
@@ -133,16 +137,28 @@ class Device:
             C.c_void_p(stream)))
         return rgb, rgba
 
-    def render_device_sampled(self, handle, camera, samples_per_axis, want_rgb=True, want_rgba8=True):
-        """render_device with samples_per_axis squared samples per pixel (whole frame; the
-        reference has one sample per pixel, src/scene/cameras.rs:53-54)."""
+    def render_device_sampled(self, handle, camera, samples_per_axis, rank=0, world=1, want_rgb=True, want_rgba8=True,
+                              out_rgb=None, out_rgba8=None):
+        """render_device with samples_per_axis squared samples per pixel (the reference has one
+        sample per pixel, src/scene/cameras.rs:53-54).  world > 1: compact buffers of
+        compact_pixels_sampled() pixels, samples_per_axis 1, 2, 4 or 8."""
         torch = self.torch
         cam = camera.to_abi() if hasattr(camera, "to_abi") else camera
-        rgb = torch.empty((cam.height, cam.width, 3), dtype=torch.float32, device=self.tdev) if want_rgb else None
-        rgba = torch.empty((cam.height, cam.width, 4), dtype=torch.uint8, device=self.tdev) if want_rgba8 else None
+        s = int(samples_per_axis)
+        if world == 1:
+            shape3, shape4 = (cam.height, cam.width, 3), (cam.height, cam.width, 4)
+        else:
+            n = compact_pixels_sampled(cam.width, cam.height, s, rank, world)
+            shape3, shape4 = (n, 3), (n, 4)
+        rgb = rgba = None
+        if want_rgb:
+            rgb = out_rgb if out_rgb is not None else torch.empty(shape3, dtype=torch.float32, device=self.tdev)
+        if want_rgba8:
+            rgba = out_rgba8 if out_rgba8 is not None else torch.empty(shape4, dtype=torch.uint8, device=self.tdev)
+        tiling = abi.rtk_tiling(rank, world)
         stream = torch.cuda.current_stream(self.tdev).cuda_stream
         _check(library().rtk_render_device_sampled(
-            self.ctx, handle.handle, C.byref(cam), int(samples_per_axis),
+            self.ctx, handle.handle, C.byref(cam), s, C.byref(tiling),
             C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
             C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
             C.c_void_p(stream)))
@@ -199,7 +215,7 @@ class Device:
         return out
 
     def untile(self, width, height, world, slot_pixels, rgb_compact=None, rgba8_compact=None, out_rgb=None,
-               out_rgba8=None, rank_stride_bytes=None):
+               out_rgba8=None, rank_stride_bytes=None, samples_per_axis=1):
         """Compact per-rank tile buffers -> row-major frames (device tensors).  By default the ranks'
         buffers lie end to end, `slot_pixels` each; with `rank_stride_bytes` every rank's FP32 and
         RGBA8 buffers start that many bytes after the previous rank's (one gathered message per rank)."""
@@ -215,7 +231,12 @@ class Device:
                 C.c_void_p(rgba8_compact.data_ptr()) if rgba8_compact is not None else None,
                 C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
                 C.c_void_p(stream))
-        if rank_stride_bytes is None:
+        if samples_per_axis != 1:  # buffers of sampled, tiled renders: (32/s) x (8/s) tiles
+            rgb_stride = rank_stride_bytes if rank_stride_bytes is not None else slot_pixels * 12
+            px_stride = rank_stride_bytes if rank_stride_bytes is not None else slot_pixels * 4
+            _check(library().rtk_untile_sampled(self.ctx, width, height, int(samples_per_axis), world, rgb_stride, px_stride,
+                                                *ptrs))
+        elif rank_stride_bytes is None:
             _check(library().rtk_untile(self.ctx, width, height, world, slot_pixels, *ptrs))
         else:
             _check(library().rtk_untile_strided(self.ctx, width, height, world, rank_stride_bytes, rank_stride_bytes, *ptrs))

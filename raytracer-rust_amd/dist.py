@@ -34,6 +34,15 @@ def slot_pixels(width, height, world):
     return tiles_for_rank(width, height, 0, world) * TILE_PIXELS
 
 
+def slot_pixels_sampled(width, height, samples_per_axis, world):
+    """The same for sampled renders: the ranks tile the SAMPLE frame, and a 32x8 tile of samples
+    becomes a (32/s) x (8/s) tile of pixels (s = 1, 2, 4, 8)."""
+    s = int(samples_per_axis)
+    if s not in (1, 2, 4, 8):
+        raise ValueError("tiled sampled renders need samples_per_axis 1, 2, 4 or 8")
+    return tiles_for_rank(width * s, height * s, 0, world) * (TILE_PIXELS // (s * s))
+
+
 def tile_rect(width, height, tile):
     """Pixel rectangle (x0, y0, x1, y1) of a global tile index, clipped to the frame."""
     tx, _ = tile_grid(width, height)
@@ -50,6 +59,25 @@ def untile_host(width, height, world, slot, compact, channels):
         rank, k = tile % world, tile // world
         x0, y0, x1, y1 = tile_rect(width, height, tile)
         block = compact[rank * slot + k * TILE_PIXELS: rank * slot + (k + 1) * TILE_PIXELS].reshape(TILE_H, TILE_W, channels)
+        frame[y0:y1, x0:x1] = block[: y1 - y0, : x1 - x0]
+    return frame
+
+
+def untile_host_sampled(width, height, samples_per_axis, world, slot, compact, channels):
+    """The same for the (32/s) x (8/s) pixel tiles of a sampled, tiled render."""
+    s = int(samples_per_axis)
+    tw, th = TILE_W // s, TILE_H // s
+    per_tile = tw * th
+    compact = np.asarray(compact).reshape(world * slot, channels)
+    frame = np.zeros((height, width, channels), dtype=compact.dtype)
+    tx, ty = tile_grid(width * s, height * s)
+    for tile in range(tx * ty):
+        rank, k = tile % world, tile // world
+        x0, y0 = (tile % tx) * tw, (tile // tx) * th
+        x1, y1 = min(x0 + tw, width), min(y0 + th, height)
+        if x0 >= width or y0 >= height:
+            continue
+        block = compact[rank * slot + k * per_tile: rank * slot + (k + 1) * per_tile].reshape(th, tw, channels)
         frame[y0:y1, x0:x1] = block[: y1 - y0, : x1 - x0]
     return frame
 
@@ -77,7 +105,7 @@ class DistributedRenderer:
     DEPTH = 2
 
     def __init__(self, width, height, group=None, want_rgb=True, want_rgba8=True, tensor_device=None,
-                 render_compact=None, untile=None, always_gather=False):
+                 render_compact=None, untile=None, always_gather=False, samples_per_axis=1):
         import collections
 
         import torch
@@ -88,7 +116,9 @@ class DistributedRenderer:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.width, self.height = width, height
-        self.slot = slot_pixels(width, height, self.world)
+        self.samples_per_axis = int(samples_per_axis)
+        self.slot = (slot_pixels(width, height, self.world) if self.samples_per_axis == 1 or self.world == 1
+                     else slot_pixels_sampled(width, height, self.samples_per_axis, self.world))
         self.want_rgb, self.want_rgba8 = want_rgb, want_rgba8
         self.render_compact, self.untile = render_compact, untile
         dev = tensor_device if tensor_device is not None else torch.device("cpu")
@@ -159,13 +189,20 @@ class DistributedRenderer:
             yield self.collect()
 
 
-def gpu_renderer(device, handle, camera, group=None, want_rgb=True, want_rgba8=True, always_gather=False):
-    """DistributedRenderer wired to the HIP path: compact tile render + device untile."""
+def gpu_renderer(device, handle, camera, group=None, want_rgb=True, want_rgba8=True, always_gather=False,
+                 samples_per_axis=1):
+    """DistributedRenderer wired to the HIP path: compact tile render + device untile.
+    samples_per_axis > 1 (2, 4 or 8 when there is more than one rank): that many squared samples per pixel."""
     cam = camera.to_abi() if hasattr(camera, "to_abi") else camera
     w, h = cam.width, cam.height
+    spa = int(samples_per_axis)
 
     def render_compact(rank, world, out_rgb, out_rgba8):
-        _render_compact(device, handle, cam, rank, world, out_rgb, out_rgba8)
+        if spa == 1:
+            _render_compact(device, handle, cam, rank, world, out_rgb, out_rgba8)
+        else:
+            device.render_device_sampled(handle, cam, spa, rank, max(world, 1), out_rgb is not None, out_rgba8 is not None,
+                                         out_rgb, out_rgba8)
 
     frames = {}
 
@@ -177,9 +214,9 @@ def gpu_renderer(device, handle, camera, group=None, want_rgb=True, want_rgba8=T
         if rgba0 is not None and "rgba8" not in frames:
             frames["rgba8"] = torch.empty((h, w, 4), dtype=torch.uint8, device=device.tdev)
         return device.untile(w, h, world, slot_pixels(w, h, world), rgb0, rgba0, frames.get("rgb"), frames.get("rgba8"),
-                             rank_stride_bytes=stride_bytes)
+                             rank_stride_bytes=stride_bytes, samples_per_axis=spa)
 
-    return DistributedRenderer(w, h, group, want_rgb, want_rgba8, device.tdev, render_compact, untile, always_gather)
+    return DistributedRenderer(w, h, group, want_rgb, want_rgba8, device.tdev, render_compact, untile, always_gather, spa)
 
 
 def _render_compact(device, handle, cam, rank, world, out_rgb, out_rgba8):

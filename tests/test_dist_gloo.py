@@ -24,7 +24,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, w, h, out_path):
+def _worker(rank, world, port, w, h, out_path, spa=1):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -38,32 +38,41 @@ def _worker(rank, world, port, w, h, out_path):
     scene, camera = rtk.synthetic.config("C2g", w, h)
 
     def render_compact(r, wd, out_rgb, out_rgba8):
-        # what rtk_render_device writes for tiling {r, wd}: local tile k = global tile k*wd + r
-        tx, ty = rdist.tile_grid(w, h)
+        # what rtk_render_device(_sampled) writes for tiling {r, wd}: local tile k = global tile k*wd + r
+        # of the (sample) frame, a (32/s) x (8/s) block of pixels
+        tw, th = rdist.TILE_W // spa, rdist.TILE_H // spa
+        per_tile = tw * th
+        tx, ty = rdist.tile_grid(w * spa, h * spa)
         out_rgb.zero_()
         out_rgba8.zero_()
         k = 0
         for tile in range(r, tx * ty, wd):
-            x0, y0, x1, y1 = rdist.tile_rect(w, h, tile)
-            rgb, rgba, _ = ob.render(scene, camera, rect=(x0, y0, x1, y1))
-            block3 = np.zeros((rdist.TILE_H, rdist.TILE_W, 3), np.float32)
-            block4 = np.zeros((rdist.TILE_H, rdist.TILE_W, 4), np.uint8)
-            block3[: y1 - y0, : x1 - x0] = rgb.astype(np.float32)
-            block4[: y1 - y0, : x1 - x0] = rgba
-            out_rgb[k * 256:(k + 1) * 256] = torch.from_numpy(block3.reshape(256, 3))
-            out_rgba8[k * 256:(k + 1) * 256] = torch.from_numpy(block4.reshape(256, 4))
+            x0, y0 = (tile % tx) * tw, (tile // tx) * th
+            x1, y1 = min(x0 + tw, w), min(y0 + th, h)
+            block3 = np.zeros((th, tw, 3), np.float32)
+            block4 = np.zeros((th, tw, 4), np.uint8)
+            if x0 < w and y0 < h:
+                rgb, rgba, _ = ob.render(scene, camera, rect=(x0, y0, x1, y1), samples_per_axis=spa)
+                block3[: y1 - y0, : x1 - x0] = rgb.astype(np.float32)
+                block4[: y1 - y0, : x1 - x0] = rgba
+            out_rgb[k * per_tile:(k + 1) * per_tile] = torch.from_numpy(block3.reshape(per_tile, 3))
+            out_rgba8[k * per_tile:(k + 1) * per_tile] = torch.from_numpy(block4.reshape(per_tile, 4))
             k += 1
-        assert k == rdist.tiles_for_rank(w, h, r, wd)
+        assert k == rdist.tiles_for_rank(w * spa, h * spa, r, wd)
 
     def untile(message, rgb0, rgba0, stride_bytes):
         # one message per rank: its FP32 tiles, then its RGBA8 tiles
-        slot = rdist.slot_pixels(w, h, world)
+        slot = rdist.slot_pixels_sampled(w, h, spa, world)
+        assert slot == rdist.slot_pixels(w, h, world) or spa > 1
         assert message.shape == (world, stride_bytes) and stride_bytes == slot * 16
         g_rgb = np.concatenate([message[r, : slot * 12].numpy().view(np.float32).reshape(slot, 3) for r in range(world)])
         g_rgba8 = np.concatenate([message[r, slot * 12:].numpy().reshape(slot, 4) for r in range(world)])
-        return (rdist.untile_host(w, h, world, slot, g_rgb, 3), rdist.untile_host(w, h, world, slot, g_rgba8, 4))
+        if spa == 1:
+            return (rdist.untile_host(w, h, world, slot, g_rgb, 3), rdist.untile_host(w, h, world, slot, g_rgba8, 4))
+        return (rdist.untile_host_sampled(w, h, spa, world, slot, g_rgb, 3),
+                rdist.untile_host_sampled(w, h, spa, world, slot, g_rgba8, 4))
 
-    renderer = rdist.DistributedRenderer(w, h, render_compact=render_compact, untile=untile)
+    renderer = rdist.DistributedRenderer(w, h, render_compact=render_compact, untile=untile, samples_per_axis=spa)
     assert renderer.world == world and renderer.rank == rank
     rgb, rgba = renderer.frame()
     if rank == 0:
@@ -99,6 +108,17 @@ def test_multi_rank_frame_equals_single_rank(rtk, oracle, tmp_path, world, w, h)
     got = np.load(out)
     scene, camera = rtk.synthetic.config("C2g", w, h)
     rgb, rgba, _ = oracle.render(scene, camera)
+    assert np.array_equal(got["rgba"], rgba)
+    assert np.array_equal(got["rgb"], rgb.astype(np.float32))
+
+
+@pytest.mark.parametrize("world,w,h,spa", [(2, 50, 21, 2), (3, 23, 9, 4)])
+def test_multi_rank_sampled_frame_equals_single_rank(rtk, oracle, tmp_path, world, w, h, spa):
+    out = str(tmp_path / "frame.npz")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, out, spa), nprocs=world, join=True)
+    got = np.load(out)
+    scene, camera = rtk.synthetic.config("C2g", w, h)
+    rgb, rgba, _ = oracle.render(scene, camera, samples_per_axis=spa)
     assert np.array_equal(got["rgba"], rgba)
     assert np.array_equal(got["rgb"], rgb.astype(np.float32))
 

@@ -350,9 +350,22 @@ static void cluster_order(std::vector<double4>& exact, std::vector<uint32_t>& ob
   object.swap(o2);
 }
 
+static int scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle** out);
+
 int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle** out) {
   if (!ctx || !scene || !out) return fail(RTK_ERR_INVALID, "rtk_scene_upload: null argument");
   *out = nullptr;
+  // the host-side record arrays are std::vectors: nothing may unwind through the C boundary
+  try {
+    return scene_upload(ctx, scene, out);
+  } catch (const std::bad_alloc&) {
+    return fail(RTK_ERR_NOMEM, "rtk_scene_upload: out of host memory");
+  } catch (...) {
+    return fail(RTK_ERR_INVALID, "rtk_scene_upload: unexpected failure while flattening the scene");
+  }
+}
+
+static int scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle** out) {
   if ((scene->n_objects && !scene->objects) || (scene->n_lights && !scene->lights))
     return fail(RTK_ERR_INVALID, "rtk_scene_upload: null object or light array");
   if (scene->max_depth > RTK_MAX_DEPTH_LIMIT) return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: max_depth above RTK_MAX_DEPTH_LIMIT");

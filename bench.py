@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 peak: 256 CUs x 2.4 GHz x 256 flop/clk/CU
+PEAK_FP64_TFLOPS = 78.6    # MI355X vector f64 peak: 256 CUs x 2.4 GHz x 128 flop/clk/CU
 FLOPS_PER_SPHERE_TEST = 26  # algorithmic flops of one ray-sphere test: oc = o-c 3, oc.d 5, oc.oc - r^2 6, disc 3, sqrt 1, two roots 4, two range tests 4
 FLOPS_PER_PLANE_TEST = 8
 
@@ -192,6 +193,11 @@ def main():
                 "measured_valu_busy": measured.get("valu_busy"),
                 "measured_valu_lane_util": measured.get("valu_lane_util"),
                 "measured_valu_issue_util": measured.get("valu_issue_util"),
+                # flops the kernel really executes (PMC instruction mix x active lanes), against the vector peaks
+                "executed_f64_TFLOPs": measured.get("executed_f64_tflops"),
+                "executed_f64_frac_of_peak": (measured["executed_f64_tflops"] / PEAK_FP64_TFLOPS
+                                              if measured.get("executed_f64_tflops") else None),
+                "executed_f32_TFLOPs": measured.get("executed_f32_tflops"),
                 "note": "achieved = algorithmic flops of the reference's sweep (26 per ray-sphere test, 8 per ray-plane "
                         "test, every ray against every object) / HIP-event time of the kernel that traces the rays "
                         "(for up to 4 lights it also shades and stores: kernel_ms = all_kernels_ms). The kernel culls "

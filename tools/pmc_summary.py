@@ -51,6 +51,13 @@ for name, counters in sorted(agg.items()):
         t32 = m.get("SQ_INSTS_VALU_TRANS_F32", 0)
         rest = m["SQ_INSTS_VALU"] - f64 - t64 - t32
         d["f64_share_of_valu_insts"] = (f64 + t64) / m["SQ_INSTS_VALU"]
+        if d.get("avg_ms") and d.get("valu_lane_util"):
+            # flops actually executed: wave64 instructions x 64 lanes x share of lanes active (fma = 2)
+            lanes = 64.0 * d["valu_lane_util"]
+            f64_flops = (m.get("SQ_INSTS_VALU_ADD_F64", 0) + m.get("SQ_INSTS_VALU_MUL_F64", 0) + 2.0 * m["SQ_INSTS_VALU_FMA_F64"]) * lanes
+            f32_flops = (m.get("SQ_INSTS_VALU_ADD_F32", 0) + m.get("SQ_INSTS_VALU_MUL_F32", 0) + 2.0 * m.get("SQ_INSTS_VALU_FMA_F32", 0)) * lanes
+            d["executed_f64_tflops"] = f64_flops / (d["avg_ms"] * 1e-3) / 1e12
+            d["executed_f32_tflops"] = f32_flops / (d["avg_ms"] * 1e-3) / 1e12
         d["valu_busy_from_mix"] = (4.0 * f64 + 16.0 * t64 + 8.0 * t32 + 2.0 * rest) / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0)
     if "SQ_WAVES" in m and "SQ_INSTS_VALU" in m:
         d["valu_per_wave"] = m["SQ_INSTS_VALU"] / m["SQ_WAVES"]
@@ -82,6 +89,8 @@ if "--measured" in sys.argv:
         "valu_busy": d.get("valu_busy_from_mix"),
         "f64_share_of_valu_insts": d.get("f64_share_of_valu_insts"),
         "valu_lane_util": d.get("valu_lane_util"),
+        "executed_f64_tflops": d.get("executed_f64_tflops"),
+        "executed_f32_tflops": d.get("executed_f32_tflops"),
         "avg_waves_per_simd": d.get("avg_waves_per_simd"),
         "clock_GHz": d.get("clock_GHz"),
         "source": src,

@@ -41,7 +41,41 @@ struct StackEntry {
   int depth;
 };
 
-template <bool SECONDARY, bool PRIMARY_FILTER, int LB, bool WIDE>
+// Scenes of a handful of objects (the reference's bundled scene has three): every object is
+// intersected exactly, in object order; no filter records, no clusters.
+constexpr uint32_t kBruteObjects = 8;
+__device__ __forceinline__ void closest_brute(const DevScene& S, bool active, V3 o, V3 d, Closest& best) {
+  closest_init(best);
+  const bool track = S.track_n1 != 0;
+  if (!active) return;
+  for (uint32_t obj = 0; obj < S.n_objects; ++obj) {
+    double t0, t1;
+    const int n = intersect_object(S.objects[obj], o, d, 0.0, t0, t1);
+    if (n >= 1) closest_consider(best, t0, obj, track);
+    if (n == 2) closest_consider(best, t1, obj, track);
+  }
+}
+// `Scene::is_shadowed` (src/scene.rs:208-225): one shadow ray per light until one is blocked.
+__device__ __forceinline__ bool shadow_brute(const DevScene& S, bool active, V3 p, unsigned& n_rays) {
+  if (!active) return false;
+  for (uint32_t k = 0; k < S.n_lights; ++k) {
+    ++n_rays;
+    const DevLight& L = S.lights[k];
+    const V3 lv = ld3(L.pos) - p;
+    const double lw = L.pos[3] - 1.0;
+    const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+    const V3 d = {lv.x / m, lv.y / m, lv.z / m};
+    const double dw = lw / m;
+    for (uint32_t obj = 0; obj < S.n_objects; ++obj) {
+      double t0, t1;
+      const int n = intersect_object(S.objects[obj], p, d, dw, t0, t1);
+      if ((n >= 1 && t0 > 0.0 && t0 < m) || (n == 2 && t1 > 0.0 && t1 < m)) return true;
+    }
+  }
+  return false;
+}
+
+template <bool SECONDARY, bool PRIMARY_FILTER, int LB, bool WIDE, bool BRUTE = false>
 __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restrict__ prim,
                                         const float4* __restrict__ prim_cluster, bool valid, V3 o,
                                         V3 d, unsigned& c_primary, unsigned& c_shadow, unsigned& c_secondary,
@@ -83,7 +117,9 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
         ++c_secondary;
     }
     Closest best;
-    if (PRIMARY_FILTER && (!SECONDARY || iter == 0))
+    if (BRUTE)
+      closest_brute(S, have, ro, rd, best);
+    else if (PRIMARY_FILTER && (!SECONDARY || iter == 0))
       closest_primary(S, prim, prim_cluster, have, ro, rd, best, c_exact);
     else
       closest_general<WIDE>(S, have, ro, rd, best, c_exact);
@@ -152,7 +188,7 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
       }
     }
 
-    const bool in_shadow = shadow_sweeps<LB, WIDE>(S, hit, over, c_shadow, c_exact);
+    const bool in_shadow = BRUTE ? shadow_brute(S, hit, over, c_shadow) : shadow_sweeps<LB, WIDE>(S, hit, over, c_shadow, c_exact);
 
     if (hit) {
       const DevObject& ob = S.objects[obj];
@@ -169,7 +205,7 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
 // `Camera::render` (src/scene/cameras.rs:72-85): ray generation (cameras.rs:52-69 with the
 // matrix inverse hoisted to the host), trace, and the framebuffer store
 // (src/graphics.rs:44-46, 59-74).
-template <bool SECONDARY, int LB, bool WIDE>
+template <bool SECONDARY, int LB, bool WIDE, bool BRUTE = false>
 __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                         const float4* __restrict__ prim_cluster, RenderTarget T,
                                                         DevCounters* counters) {
@@ -188,7 +224,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera
   const V3 dir = camera_ray_direction(C, x, y);  // cameras.rs:52-69
 
   unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
-  V3 color = trace_ray<SECONDARY, true, LB, WIDE>(S, prim, prim_cluster, valid, origin, dir, c_primary, c_shadow, c_secondary, c_exact);
+  V3 color = trace_ray<SECONDARY, true, LB, WIDE, BRUTE>(S, prim, prim_cluster, valid, origin, dir, c_primary, c_shadow, c_secondary, c_exact);
 
   // ---- framebuffer store, transposed through LDS so that every wavefront writes whole
   // 128-byte (RGBA8) / 384-byte (FP32 RGB) tile rows
@@ -456,6 +492,10 @@ hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, 
                          const float4* prim_cluster, const RenderTarget& T, DevCounters* counters) {
   if (T.n_local_tiles == 0) return hipSuccess;
   dim3 grid(T.n_local_tiles);
+  if (S.n_objects <= kBruteObjects) {
+    hipLaunchKernelGGL((render_kernel<true, 1, false, true>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters);
+    return hipGetLastError();
+  }
   const int lb = light_batch_for(S.n_lights);
   if (S.n_spheres >= kWideScene) return launch_render_lb<true>(lb, grid, st, S, C, prim, prim_cluster, T, counters);
   return launch_render_lb<false>(lb, grid, st, S, C, prim, prim_cluster, T, counters);

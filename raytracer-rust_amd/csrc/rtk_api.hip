@@ -15,6 +15,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
+#include <functional>
 #include <utility>
 #include <vector>
 
@@ -141,6 +143,7 @@ uint32_t round_up_to(uint32_t n, uint32_t m) { return (n + m - 1) / m * m; }
 // ---------------------------------------------------------------- opaque handles
 struct rtk_scene_handle {
   rtk::DevScene dev{};
+  void* d_block = nullptr;  // the one device allocation every pointer below points into
   void* d_objects = nullptr;
   void* d_lights = nullptr;
   void* d_filter = nullptr;
@@ -305,10 +308,7 @@ void rtk_destroy(rtk_context* ctx) {
 void rtk_scene_release(rtk_context* ctx, rtk_scene_handle* h) {
   if (!h) return;
   if (ctx) (void)hipSetDevice(ctx->device);
-  void* ptrs[] = {h->d_objects, h->d_lights, h->d_filter, h->d_exact, h->d_sph_object, h->d_plane_object, h->d_prim,
-                  h->d_light_filter, h->d_k_table, h->d_sph_tab, h->d_prim_ball, h->d_sph_ball, h->d_cluster_ball, h->d_prim_cluster, h->d_pattern_inv, h->d_light_kind};
-  for (void* p : ptrs)
-    if (p) (void)hipFree(p);
+  if (h->d_block) (void)hipFree(h->d_block);
   delete h;
 }
 
@@ -379,55 +379,97 @@ static int scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_hand
   std::vector<double> pattern_inv;  // stays empty unless some pattern has a transform of its own
   bool track_n1 = false, any_secondary = false;
 
-  for (uint32_t i = 0; i < scene->n_objects; ++i) {
-    const rtk_object& src = scene->objects[i];
-    if (src.kind != RTK_SPHERE && src.kind != RTK_PLANE) return fail(RTK_ERR_INVALID, "rtk_scene_upload: unknown object kind");
-    if (src.material.texture_kind > RTK_TEX_STRIPED) return fail(RTK_ERR_INVALID, "rtk_scene_upload: unknown texture kind");
-    for (double v : src.transform)
-      if (!std::isfinite(v))  // the reference panics on the NaN distances such a transform produces (src/scene.rs:164-166)
-        return fail(RTK_ERR_INVALID, "rtk_scene_upload: object transform has a non-finite element");
-    if (!is_affine(src.transform))
-      return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: object transform is not affine (last row must be 0 0 0 1)");
-    if (src.kind == RTK_PLANE && src.plane_normal[3] != 0.0)
-      return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: plane_normal[3] must be 0");
-    M4 t = m4_load(src.transform), inv;
-    bool invertible = m4_invert(t, inv);
-    if (!invertible) {  // src/scene.rs:55-62: identity inverse
-      inv = m4_identity();
-      t = m4_identity();
+  // Per-object work (validation, the reference's cofactor inverse, bounding ball) is independent:
+  // large scenes split it over a few host threads.  Errors are reported for the lowest object index.
+  for (uint32_t i = 0; i < scene->n_objects && pattern_inv.empty(); ++i)
+    if (scene->objects[i].material.pattern_transformed) pattern_inv.assign(12 * (size_t)scene->n_objects, 0.0);
+  std::vector<double4> ball(scene->n_objects);
+  struct Outcome {
+    int status = RTK_OK;
+    uint32_t at = 0xffffffffu;
+    const char* message = "";
+    bool track_n1 = false, any_secondary = false;
+  };
+  auto flatten = [&](uint32_t begin, uint32_t end_, Outcome& oc) {
+    auto bad = [&](uint32_t i, int status, const char* message) {
+      oc.status = status, oc.at = i, oc.message = message;
+    };
+    for (uint32_t i = begin; i < end_; ++i) {
+      const rtk_object& src = scene->objects[i];
+      if (src.kind != RTK_SPHERE && src.kind != RTK_PLANE) return bad(i, RTK_ERR_INVALID, "rtk_scene_upload: unknown object kind");
+      if (src.material.texture_kind > RTK_TEX_STRIPED) return bad(i, RTK_ERR_INVALID, "rtk_scene_upload: unknown texture kind");
+      for (double v : src.transform)
+        if (!std::isfinite(v))  // the reference panics on the NaN distances such a transform produces (src/scene.rs:164-166)
+          return bad(i, RTK_ERR_INVALID, "rtk_scene_upload: object transform has a non-finite element");
+      if (!is_affine(src.transform))
+        return bad(i, RTK_ERR_UNSUPPORTED, "rtk_scene_upload: object transform is not affine (last row must be 0 0 0 1)");
+      if (src.kind == RTK_PLANE && src.plane_normal[3] != 0.0)
+        return bad(i, RTK_ERR_UNSUPPORTED, "rtk_scene_upload: plane_normal[3] must be 0");
+      M4 t = m4_load(src.transform), inv;
+      bool invertible = m4_invert(t, inv);
+      if (!invertible) {  // src/scene.rs:55-62: identity inverse
+        inv = m4_identity();
+        t = m4_identity();
+      }
+      DevObject& o = objects[i];
+      std::memcpy(o.inv, inv.e, sizeof o.inv);
+      std::memcpy(o.color_a, src.material.color_a, sizeof o.color_a);
+      std::memcpy(o.color_b, src.material.color_b, sizeof o.color_b);
+      o.ambient = src.material.ambient;
+      o.diffuse = src.material.diffuse;
+      o.specular = src.material.specular;
+      o.shininess = src.material.shininess;
+      o.transparency = src.material.transparency;
+      o.reflectivity = src.material.reflectivity;
+      o.refractivity = src.material.refractivity;
+      std::memcpy(o.plane_normal, src.plane_normal, sizeof o.plane_normal);
+      o.kind = src.kind;
+      o.texture_kind = src.material.texture_kind;
+      if (src.material.pattern_transformed) {
+        // `TransformPattern` (src/graphics/patterns.rs:27-35): the reference inverts per sample and
+        // samples the untransformed point when the matrix is singular
+        M4 pinv;
+        if (m4_invert(m4_load(src.material.pattern_transform), pinv)) {
+          std::memcpy(&pattern_inv[12 * (size_t)i], pinv.e, 12 * sizeof(double));
+          o.texture_kind |= 0x80000000u;
+        }
+      }
+      if (o.refractivity != 1.0) oc.track_n1 = true;
+      if (!(std::fabs(o.reflectivity) < 0.00001) || !(std::fabs(o.transparency) < 0.00001)) oc.any_secondary = true;
+      // bounding ball of the transformed unit sphere: centre = translation, radius = sigma_max
+      if (src.kind == RTK_SPHERE) ball[i] = make_double4(t.at(0, 3), t.at(1, 3), t.at(2, 3), sigma_max3(t));
     }
-    DevObject& o = objects[i];
-    std::memcpy(o.inv, inv.e, sizeof o.inv);
-    std::memcpy(o.color_a, src.material.color_a, sizeof o.color_a);
-    std::memcpy(o.color_b, src.material.color_b, sizeof o.color_b);
-    o.ambient = src.material.ambient;
-    o.diffuse = src.material.diffuse;
-    o.specular = src.material.specular;
-    o.shininess = src.material.shininess;
-    o.transparency = src.material.transparency;
-    o.reflectivity = src.material.reflectivity;
-    o.refractivity = src.material.refractivity;
-    std::memcpy(o.plane_normal, src.plane_normal, sizeof o.plane_normal);
-    o.kind = src.kind;
-    o.texture_kind = src.material.texture_kind;
-    if (src.material.pattern_transformed) {
-      // `TransformPattern` (src/graphics/patterns.rs:27-35): the reference inverts per sample and
-      // samples the untransformed point when the matrix is singular
-      M4 pinv;
-      if (m4_invert(m4_load(src.material.pattern_transform), pinv)) {
-        if (pattern_inv.empty()) pattern_inv.assign(12 * (size_t)scene->n_objects, 0.0);
-        std::memcpy(&pattern_inv[12 * (size_t)i], pinv.e, 12 * sizeof(double));
-        o.texture_kind |= 0x80000000u;
+  };
+  const uint32_t hw = std::thread::hardware_concurrency();
+  const uint32_t n_threads = scene->n_objects < 2048u ? 1u : std::max(1u, std::min({8u, hw ? hw : 1u, scene->n_objects / 1024u}));
+  std::vector<Outcome> outcomes(n_threads);
+  if (n_threads == 1) {
+    flatten(0, scene->n_objects, outcomes[0]);
+  } else {
+    std::vector<std::thread> pool;
+    const uint32_t chunk = (scene->n_objects + n_threads - 1) / n_threads;
+    pool.reserve(n_threads);
+    for (uint32_t t = 0; t < n_threads; ++t) {
+      const uint32_t begin = std::min(t * chunk, scene->n_objects), end_ = std::min((t + 1) * chunk, scene->n_objects);
+      try {
+        pool.emplace_back(flatten, begin, end_, std::ref(outcomes[t]));
+      } catch (...) {  // no thread to be had: this chunk runs here
+        flatten(begin, end_, outcomes[t]);
       }
     }
-    if (o.refractivity != 1.0) track_n1 = true;
-    if (!(std::fabs(o.reflectivity) < 0.00001) || !(std::fabs(o.transparency) < 0.00001)) any_secondary = true;
-    if (src.kind == RTK_PLANE) {
+    for (std::thread& t : pool) t.join();
+  }
+  for (const Outcome& oc : outcomes) {  // chunks are in object order: the first failure is the lowest index
+    if (oc.status != RTK_OK) return fail(oc.status, oc.message);
+    track_n1 = track_n1 || oc.track_n1;
+    any_secondary = any_secondary || oc.any_secondary;
+  }
+  for (uint32_t i = 0; i < scene->n_objects; ++i) {
+    if (scene->objects[i].kind == RTK_PLANE) {
       plane_object.push_back(i);
     } else {
-      // bounding ball of the transformed unit sphere: centre = translation, radius = sigma_max
       sph_object.push_back(i);
-      sph_exact.push_back(make_double4(t.at(0, 3), t.at(1, 3), t.at(2, 3), sigma_max3(t)));
+      sph_exact.push_back(ball[i]);
     }
   }
   for (uint32_t k = 0; k < scene->n_lights; ++k) {
@@ -564,28 +606,48 @@ static int scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_hand
 
   rtk_scene_handle* h = new (std::nothrow) rtk_scene_handle();
   if (!h) return fail(RTK_ERR_NOMEM, "rtk_scene_upload: out of host memory");
-  hipError_t e = hipSetDevice(ctx->device);
-  auto upload = [&](void** dst, const void* src, size_t bytes) {
-    if (e != hipSuccess || bytes == 0) return;
-    e = hipMalloc(dst, bytes);
-    if (e == hipSuccess) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  // One device allocation and one copy for all record arrays (each 256-byte aligned inside it);
+  // the per-camera records, which only kernels write, follow at its end.
+  struct Piece {
+    void** dst;
+    const void* src;
+    size_t bytes, offset;
   };
-  upload(&h->d_objects, objects.data(), objects.size() * sizeof(DevObject));
-  upload(&h->d_lights, lights.data(), lights.size() * sizeof(DevLight));
-  upload(&h->d_filter, filter.data(), filter.size() * sizeof(float4));
-  upload(&h->d_exact, sph_exact.data(), sph_exact.size() * sizeof(double4));
-  upload(&h->d_sph_object, sph_object.data(), sph_object.size() * sizeof(uint32_t));
-  upload(&h->d_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
-  upload(&h->d_pattern_inv, pattern_inv.data(), pattern_inv.size() * sizeof(double));
-  upload(&h->d_light_filter, light_filter.data(), light_filter.size() * sizeof(float4));
-  upload(&h->d_light_kind, light_kind.data(), light_kind.size() * sizeof(uint32_t));
-  upload(&h->d_k_table, k_table.data(), k_table.size() * sizeof(float));
-  upload(&h->d_sph_tab, sph_tab.data(), sph_tab.size() * sizeof(float4));
-  upload(&h->d_sph_ball, sph_ball.data(), sph_ball.size() * sizeof(float4));
-  upload(&h->d_cluster_ball, cluster_ball.data(), cluster_ball.size() * sizeof(float4));
-  if (e == hipSuccess && n_pad) e = hipMalloc((void**)&h->d_prim, n_pad * sizeof(float4));
-  if (e == hipSuccess && n_pad) e = hipMalloc((void**)&h->d_prim_ball, n_pad * sizeof(float4));
-  if (e == hipSuccess && n_pad) e = hipMalloc((void**)&h->d_prim_cluster, n_clusters_pad * sizeof(float4));
+  std::vector<Piece> pieces;
+  size_t total = 0;
+  auto place = [&](void** dst, const void* src, size_t bytes) {
+    *dst = nullptr;
+    if (bytes == 0) return;
+    pieces.push_back({dst, src, bytes, total});
+    total += (bytes + 255u) & ~(size_t)255u;
+  };
+  place(&h->d_objects, objects.data(), objects.size() * sizeof(DevObject));
+  place(&h->d_lights, lights.data(), lights.size() * sizeof(DevLight));
+  place(&h->d_filter, filter.data(), filter.size() * sizeof(float4));
+  place(&h->d_exact, sph_exact.data(), sph_exact.size() * sizeof(double4));
+  place(&h->d_sph_object, sph_object.data(), sph_object.size() * sizeof(uint32_t));
+  place(&h->d_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
+  place(&h->d_pattern_inv, pattern_inv.data(), pattern_inv.size() * sizeof(double));
+  place(&h->d_light_filter, light_filter.data(), light_filter.size() * sizeof(float4));
+  place(&h->d_light_kind, light_kind.data(), light_kind.size() * sizeof(uint32_t));
+  place(&h->d_k_table, k_table.data(), k_table.size() * sizeof(float));
+  place(&h->d_sph_tab, sph_tab.data(), sph_tab.size() * sizeof(float4));
+  place(&h->d_sph_ball, sph_ball.data(), sph_ball.size() * sizeof(float4));
+  place(&h->d_cluster_ball, cluster_ball.data(), cluster_ball.size() * sizeof(float4));
+  const size_t copied = total;
+  place((void**)&h->d_prim, nullptr, n_pad * sizeof(float4));
+  place((void**)&h->d_prim_ball, nullptr, n_pad * sizeof(float4));
+  place((void**)&h->d_prim_cluster, nullptr, n_pad ? n_clusters_pad * sizeof(float4) : 0);
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess && total) {
+    std::vector<unsigned char> staged(copied, 0);
+    for (const Piece& p : pieces)
+      if (p.src) std::memcpy(staged.data() + p.offset, p.src, p.bytes);
+    e = hipMalloc(&h->d_block, total);
+    if (e == hipSuccess && copied) e = hipMemcpy(h->d_block, staged.data(), copied, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+      for (const Piece& p : pieces) *p.dst = (unsigned char*)h->d_block + p.offset;
+  }
   if (e != hipSuccess) {
     rtk_scene_release(ctx, h);
     return fail_hip(e, "rtk_scene_upload");

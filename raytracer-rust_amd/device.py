@@ -198,8 +198,10 @@ class Device:
         """`Camera::render` through the host-buffer entry point; returns a Canvas."""
         s = scene.to_abi() if hasattr(scene, "to_abi") else scene
         cam = camera.to_abi() if hasattr(camera, "to_abi") else camera
-        rgb = np.empty((cam.height, cam.width, 3), dtype=np.float32)
-        rgba = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
+        # page-locked host buffers: the copy back runs at PCIe speed and the pages are not faulted in per frame
+        torch = self.torch
+        rgb = torch.empty((cam.height, cam.width, 3), dtype=torch.float32, pin_memory=True).numpy()
+        rgba = torch.empty((cam.height, cam.width, 4), dtype=torch.uint8, pin_memory=True).numpy()
         st = abi.rtk_stats()
         _check(library().rtk_render_sampled(self.ctx, C.byref(s), C.byref(cam), int(samples_per_axis),
                                             rgb.ctypes.data_as(C.c_void_p), rgba.ctypes.data_as(C.c_void_p), C.byref(st)))

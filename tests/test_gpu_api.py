@@ -303,3 +303,22 @@ def test_distributed_renderer_sampled_single_process(rtk, dev):
         assert torch.equal(f_rgb, want_rgb) and torch.equal(f_rgba, want_rgba)
         frames += 1
     assert frames == 3
+
+
+def test_example_script_reproduces_the_reference_image(tmp_path):
+    """examples/render_scene.py is the reference's `main` on the GPU: its PNG decodes to output.png's pixels."""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+
+    from PIL import Image
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "output.png"
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "render_scene.py"),
+                        os.path.join(root, "tests", "golden", "test01.yaml"), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    meta = json.load(open(os.path.join(root, "tests", "golden", "output_meta.json")))
+    assert hashlib.sha256(np.asarray(Image.open(out)).tobytes()).hexdigest() == meta["decoded_rgba_sha256"]
+    assert "21939338 rays" in r.stdout

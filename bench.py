@@ -109,6 +109,20 @@ def main():
     dev = device.Device(local_rank)
     handle = dev.upload(scene)  # the scene is resident in HBM before anything is timed
     renderer = rdist.gpu_renderer(dev, handle, camera, group=None)
+    # More than one GPU: rank 0 receives all tiles and sends none, so it can take a larger share of
+    # the frame.  The share is timed on this machine before the warm-up (RTK_ROOT_SHARE fixes it).
+    root_share = 1
+    if world > 1:
+        try:
+            if os.environ.get("RTK_ROOT_SHARE"):
+                renderer.set_root_share(int(os.environ["RTK_ROOT_SHARE"]))
+            else:
+                renderer.autotune(sync=torch.cuda.synchronize)
+        except Exception as exc:  # the same failure on every rank: fall back to the plain round-robin
+            print(f"rank {rank}: partition tuning failed ({exc}); using equal shares", file=sys.stderr, flush=True)
+            renderer.in_flight.clear()
+            renderer.set_root_share(1)
+        root_share = renderer.root_share
 
     def sync_all():
         torch.cuda.synchronize()
@@ -172,7 +186,8 @@ def main():
                 "workload": f"{args.workload}: {n_sph} spheres + {n_pl} plane(s), {len(scene.lights)} lights, "
                             f"{camera.width}x{camera.height}, 1 spp, opaque materials",
                 "rays_per_frame": int(frame_rays),
-                "tiles": "32x8 px tiles dealt round-robin to ranks; FP32 RGB + RGBA8 gathered to rank 0",
+                "tiles": "32x8 px tiles dealt round-robin to ranks; FP32 RGB + RGBA8 gathered to rank 0"
+                         + (f"; rank 0 renders {root_share} of every {world - 1 + root_share} tiles" if world > 1 else ""),
                 "precision": "every decision and colour in f64 (the reference's formulas); FP32 only in the conservative culling tests; FP32 RGB + RGBA8 store",
             },
             "pct_fp32_valu_peak": 100.0 * (frame_rays * fpr * args.steps / elapsed / 1e12) / (PEAK_FP32_TFLOPS * world),

@@ -105,7 +105,7 @@ class DistributedRenderer:
     DEPTH = 2
 
     def __init__(self, width, height, group=None, want_rgb=True, want_rgba8=True, tensor_device=None,
-                 render_compact=None, untile=None, always_gather=False, samples_per_axis=1):
+                 render_compact=None, untile=None, always_gather=False, samples_per_axis=1, root_share=1):
         import collections
 
         import torch
@@ -117,25 +117,45 @@ class DistributedRenderer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.width, self.height = width, height
         self.samples_per_axis = int(samples_per_axis)
-        self.slot = (slot_pixels(width, height, self.world) if self.samples_per_axis == 1 or self.world == 1
-                     else slot_pixels_sampled(width, height, self.samples_per_axis, self.world))
         self.want_rgb, self.want_rgba8 = want_rgb, want_rgba8
         self.render_compact, self.untile = render_compact, untile
-        dev = tensor_device if tensor_device is not None else torch.device("cpu")
-        self.rgb_bytes = self.slot * 12 if want_rgb else 0
-        self.message_bytes = self.rgb_bytes + (self.slot * 4 if want_rgba8 else 0)
-        self.messages = [torch.zeros(self.message_bytes, dtype=torch.uint8, device=dev) for _ in range(self.DEPTH)]
-        self.gathered = None
-        if self.rank == 0 and self.world > 1:
-            self.gathered = [torch.zeros((self.world, self.message_bytes), dtype=torch.uint8, device=dev)
-                             for _ in range(self.DEPTH)]
+        self.tensor_device = tensor_device if tensor_device is not None else torch.device("cpu")
         # always_gather: a single rank still sends its frame through the process group (to itself),
         # which exercises the collective path on one GPU
         self.always_gather = bool(always_gather) and dist.is_initialized()
+        self.in_flight = collections.deque()  # (buffer index, pending communication), oldest first
+        self.submitted = 0
+        self.set_root_share(root_share)
+
+    def set_root_share(self, root_share):
+        """Rank 0 receives every other rank's tiles and sends none, so on short frames the exchange,
+        not the render, sets the pace.  root_share = a > 1 deals the tiles to `world - 1 + a` virtual
+        ranks and gives a of them to rank 0: it renders a / (world - 1 + a) of the frame, the other
+        ranks send correspondingly less.  a = 1 is the plain round-robin with one gather per frame;
+        a > 1 exchanges with one send per rank and matching receives on rank 0 (message sizes of
+        rank 0's and the other ranks' shares differ, which a gather cannot express)."""
+        if self.in_flight:
+            raise RuntimeError("DistributedRenderer: collect() the frames in flight before changing the partition")
+        a = int(root_share)
+        if a < 1:
+            raise ValueError("root_share must be at least 1")
+        if self.world == 1:
+            a = 1
+        torch, dev = self.torch, self.tensor_device
+        self.root_share = a
+        self.virtual_world = self.world - 1 + a
+        vw = self.virtual_world
+        self.slot = (slot_pixels(self.width, self.height, vw) if self.samples_per_axis == 1 or vw == 1
+                     else slot_pixels_sampled(self.width, self.height, self.samples_per_axis, vw))
+        self.rgb_bytes = self.slot * 12 if self.want_rgb else 0
+        self.message_bytes = self.rgb_bytes + (self.slot * 4 if self.want_rgba8 else 0)
+        self.messages = self.gathered = None
+        if a == 1 or self.rank != 0:  # with a > 1 rank 0 renders straight into its rows of the gathered buffer
+            self.messages = [torch.zeros(self.message_bytes, dtype=torch.uint8, device=dev) for _ in range(self.DEPTH)]
+        if self.rank == 0 and vw > 1:
+            self.gathered = [torch.zeros((vw, self.message_bytes), dtype=torch.uint8, device=dev) for _ in range(self.DEPTH)]
         if self.always_gather and self.gathered is None:
             self.gathered = [torch.zeros((1, self.message_bytes), dtype=torch.uint8, device=dev) for _ in range(self.DEPTH)]
-        self.in_flight = collections.deque()  # (buffer index, gather handle or None), oldest first
-        self.submitted = 0
 
     def _views(self, message):
         """([slot, 3] float32, [slot, 4] uint8) views of one rank's message."""
@@ -144,35 +164,80 @@ class DistributedRenderer:
         return rgb, rgba8
 
     def submit(self):
-        """Starts the next frame: this rank's tiles, then (world > 1) the gather, without waiting."""
+        """Starts the next frame: this rank's tiles, then (world > 1) the exchange, without waiting."""
         if len(self.in_flight) >= self.DEPTH:
             raise RuntimeError("DistributedRenderer: collect() a frame before submitting a third")
         i = self.submitted % self.DEPTH
         self.submitted += 1
-        rgb, rgba8 = self._views(self.messages[i])
-        self.render_compact(self.rank, self.world, rgb, rgba8)
+        dist, a, vw = self.dist, self.root_share, self.virtual_world
         work = None
-        if self.world > 1 or self.always_gather:
-            targets = list(self.gathered[i].unbind(0)) if self.rank == 0 else None
-            work = self.dist.gather(self.messages[i], gather_list=targets, dst=0, group=self.group, async_op=True)
+        if a == 1:
+            rgb, rgba8 = self._views(self.messages[i])
+            self.render_compact(self.rank, self.world, rgb, rgba8)
+            if self.world > 1 or self.always_gather:
+                targets = list(self.gathered[i].unbind(0)) if self.rank == 0 else None
+                work = [dist.gather(self.messages[i], gather_list=targets, dst=0, group=self.group, async_op=True)]
+        elif self.rank == 0:
+            for v in range(a):  # rank 0 is virtual ranks 0 .. a-1
+                rgb, rgba8 = self._views(self.gathered[i][v])
+                self.render_compact(v, vw, rgb, rgba8)
+            ops = [dist.P2POp(dist.irecv, self.gathered[i][a + r - 1], self._peer(r), self.group) for r in range(1, self.world)]
+            work = dist.batch_isend_irecv(ops)
+        else:
+            rgb, rgba8 = self._views(self.messages[i])
+            self.render_compact(a + self.rank - 1, vw, rgb, rgba8)
+            work = dist.batch_isend_irecv([dist.P2POp(dist.isend, self.messages[i], self._peer(0), self.group)])
         self.in_flight.append((i, work))
+
+    def _peer(self, group_rank):
+        """Global rank of a rank of this renderer's group (what point-to-point calls address)."""
+        return group_rank if self.group is None else self.dist.get_global_rank(self.group, group_rank)
 
     def collect(self):
         """Finishes the oldest frame in flight.  Returns (rgb, rgba8) frames on rank 0, (None, None) elsewhere."""
         i, work = self.in_flight.popleft()
+        for w in work or ():
+            w.wait()  # device tensors: the current stream waits for the exchange; host tensors: the host does
         if self.world == 1:
-            if work is not None:
-                work.wait()
             n = self.width * self.height
-            rgb, rgba8 = self._views(self.gathered[i][0] if work is not None else self.messages[i])
+            rgb, rgba8 = self._views(self.gathered[i][0] if work else self.messages[i])
             rgb = rgb[:n].view(self.height, self.width, 3) if rgb is not None else None
             rgba8 = rgba8[:n].view(self.height, self.width, 4) if rgba8 is not None else None
             return rgb, rgba8
-        work.wait()  # device tensors: the current stream waits for the gather; host tensors: the host does
         if self.rank != 0:
             return None, None
         rgb0, rgba0 = self._views(self.gathered[i][0])
         return self.untile(self.gathered[i], rgb0, rgba0, self.message_bytes)
+
+    def autotune(self, candidates=(1, 2, 3, 4, 6), frames=6, sync=None):
+        """Picks root_share by timing a short stream of frames per candidate (every rank calls this;
+        rank 0's clock decides and the choice is broadcast).  `sync` waits for the device, if any."""
+        import time
+
+        if self.world == 1:
+            return 1
+        torch, dist = self.torch, self.dist
+        best, best_t = 1, None
+        for a in candidates:
+            self.set_root_share(a)
+            for _ in self.stream(2):  # connections and buffers of this partition
+                pass
+            if sync:
+                sync()
+            dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            for _ in self.stream(frames):
+                pass
+            if sync:
+                sync()
+            dist.barrier(group=self.group)
+            t = time.perf_counter() - t0
+            if best_t is None or t < best_t:
+                best, best_t = a, t
+        choice = torch.tensor([best], dtype=torch.int64, device=self.tensor_device)
+        dist.broadcast(choice, src=self._peer(0), group=self.group)
+        self.set_root_share(int(choice.item()))
+        return self.root_share
 
     def frame(self):
         """One frame, start to finish."""
@@ -190,7 +255,7 @@ class DistributedRenderer:
 
 
 def gpu_renderer(device, handle, camera, group=None, want_rgb=True, want_rgba8=True, always_gather=False,
-                 samples_per_axis=1):
+                 samples_per_axis=1, root_share=1):
     """DistributedRenderer wired to the HIP path: compact tile render + device untile.
     samples_per_axis > 1 (2, 4 or 8 when there is more than one rank): that many squared samples per pixel."""
     cam = camera.to_abi() if hasattr(camera, "to_abi") else camera
@@ -216,7 +281,8 @@ def gpu_renderer(device, handle, camera, group=None, want_rgb=True, want_rgba8=T
         return device.untile(w, h, world, slot_pixels(w, h, world), rgb0, rgba0, frames.get("rgb"), frames.get("rgba8"),
                              rank_stride_bytes=stride_bytes, samples_per_axis=spa)
 
-    return DistributedRenderer(w, h, group, want_rgb, want_rgba8, device.tdev, render_compact, untile, always_gather, spa)
+    return DistributedRenderer(w, h, group, want_rgb, want_rgba8, device.tdev, render_compact, untile, always_gather, spa,
+                               root_share)
 
 
 def _render_compact(device, handle, cam, rank, world, out_rgb, out_rgba8):

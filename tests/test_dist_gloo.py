@@ -24,7 +24,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, w, h, out_path, spa=1):
+def _worker(rank, world, port, w, h, out_path, spa=1, root_share=1, autotune=False):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -61,19 +61,28 @@ def _worker(rank, world, port, w, h, out_path, spa=1):
         assert k == rdist.tiles_for_rank(w * spa, h * spa, r, wd)
 
     def untile(message, rgb0, rgba0, stride_bytes):
-        # one message per rank: its FP32 tiles, then its RGBA8 tiles
-        slot = rdist.slot_pixels_sampled(w, h, spa, world)
-        assert slot == rdist.slot_pixels(w, h, world) or spa > 1
-        assert message.shape == (world, stride_bytes) and stride_bytes == slot * 16
-        g_rgb = np.concatenate([message[r, : slot * 12].numpy().view(np.float32).reshape(slot, 3) for r in range(world)])
-        g_rgba8 = np.concatenate([message[r, slot * 12:].numpy().reshape(slot, 4) for r in range(world)])
+        # one message per (virtual) rank: its FP32 tiles, then its RGBA8 tiles
+        vw = message.shape[0]
+        slot = rdist.slot_pixels_sampled(w, h, spa, vw)
+        assert slot == rdist.slot_pixels(w, h, vw) or spa > 1
+        assert message.shape == (vw, stride_bytes) and stride_bytes == slot * 16
+        g_rgb = np.concatenate([message[r, : slot * 12].numpy().view(np.float32).reshape(slot, 3) for r in range(vw)])
+        g_rgba8 = np.concatenate([message[r, slot * 12:].numpy().reshape(slot, 4) for r in range(vw)])
         if spa == 1:
-            return (rdist.untile_host(w, h, world, slot, g_rgb, 3), rdist.untile_host(w, h, world, slot, g_rgba8, 4))
-        return (rdist.untile_host_sampled(w, h, spa, world, slot, g_rgb, 3),
-                rdist.untile_host_sampled(w, h, spa, world, slot, g_rgba8, 4))
+            return (rdist.untile_host(w, h, vw, slot, g_rgb, 3), rdist.untile_host(w, h, vw, slot, g_rgba8, 4))
+        return (rdist.untile_host_sampled(w, h, spa, vw, slot, g_rgb, 3),
+                rdist.untile_host_sampled(w, h, spa, vw, slot, g_rgba8, 4))
 
-    renderer = rdist.DistributedRenderer(w, h, render_compact=render_compact, untile=untile, samples_per_axis=spa)
+    renderer = rdist.DistributedRenderer(w, h, render_compact=render_compact, untile=untile, samples_per_axis=spa,
+                                         root_share=root_share)
     assert renderer.world == world and renderer.rank == rank
+    assert renderer.virtual_world == world - 1 + root_share
+    if autotune:
+        chosen = renderer.autotune(candidates=(1, 2, 3), frames=2)
+        assert chosen in (1, 2, 3) and renderer.root_share == chosen and not renderer.in_flight
+        agreed = torch.tensor([chosen])
+        tdist.all_reduce(agreed, op=tdist.ReduceOp.MAX)
+        assert int(agreed.item()) == chosen  # every rank ended on the same partition
     rgb, rgba = renderer.frame()
     if rank == 0:
         np.savez(out_path, rgb=rgb, rgba=rgba)
@@ -121,6 +130,28 @@ def test_multi_rank_sampled_frame_equals_single_rank(rtk, oracle, tmp_path, worl
     rgb, rgba, _ = oracle.render(scene, camera, samples_per_axis=spa)
     assert np.array_equal(got["rgba"], rgba)
     assert np.array_equal(got["rgb"], rgb.astype(np.float32))
+
+
+@pytest.mark.parametrize("world,w,h,spa,share", [(2, 96, 40, 1, 2), (3, 70, 19, 1, 3), (2, 50, 21, 2, 2)])
+def test_weighted_partition_equals_single_rank(rtk, oracle, tmp_path, world, w, h, spa, share):
+    """Rank 0 takes `share` of the `world - 1 + share` virtual ranks and receives the others' tiles
+    with point-to-point transfers; the frame is the single-rank frame."""
+    out = str(tmp_path / "frame.npz")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, out, spa, share), nprocs=world, join=True)
+    got = np.load(out)
+    scene, camera = rtk.synthetic.config("C2g", w, h)
+    rgb, rgba, _ = oracle.render(scene, camera, samples_per_axis=spa)
+    assert np.array_equal(got["rgba"], rgba)
+    assert np.array_equal(got["rgb"], rgb.astype(np.float32))
+
+
+def test_partition_autotune_agrees_across_ranks(rtk, oracle, tmp_path):
+    out = str(tmp_path / "frame.npz")
+    mp.spawn(_worker, args=(2, _free_port(), 64, 24, out, 1, 1, True), nprocs=2, join=True)
+    got = np.load(out)
+    scene, camera = rtk.synthetic.config("C2g", 64, 24)
+    _, rgba, _ = oracle.render(scene, camera)
+    assert np.array_equal(got["rgba"], rgba)
 
 
 def test_untile_host_round_trip(rtk):

@@ -117,7 +117,7 @@ def main():
             if os.environ.get("RTK_ROOT_SHARE"):
                 renderer.set_root_share(int(os.environ["RTK_ROOT_SHARE"]))
             else:
-                renderer.autotune(sync=torch.cuda.synchronize)
+                renderer.autotune(frames=12, sync=torch.cuda.synchronize)
         except Exception as exc:  # the same failure on every rank: fall back to the plain round-robin
             print(f"rank {rank}: partition tuning failed ({exc}); using equal shares", file=sys.stderr, flush=True)
             renderer.in_flight.clear()

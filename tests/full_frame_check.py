@@ -1,7 +1,7 @@
 """Whole-frame parity at the benchmark's size: the device frame of a configuration against the
 CPU oracle, band by band (a 10,000-sphere 4K frame is minutes of oracle time on 16 threads).
 
-    python tools/full_frame_check.py [C4] [bands]
+    python tests/full_frame_check.py [C4] [bands]
 """
 import importlib, os, sys, time
 import numpy as np

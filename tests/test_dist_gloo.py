@@ -132,7 +132,7 @@ def test_multi_rank_sampled_frame_equals_single_rank(rtk, oracle, tmp_path, worl
     assert np.array_equal(got["rgb"], rgb.astype(np.float32))
 
 
-@pytest.mark.parametrize("world,w,h,spa,share", [(2, 96, 40, 1, 2), (3, 70, 19, 1, 3), (2, 50, 21, 2, 2)])
+@pytest.mark.parametrize("world,w,h,spa,share", [(2, 96, 40, 1, 2), (3, 70, 19, 1, 3), (2, 50, 21, 2, 2), (4, 64, 24, 1, 6)])
 def test_weighted_partition_equals_single_rank(rtk, oracle, tmp_path, world, w, h, spa, share):
     """Rank 0 takes `share` of the `world - 1 + share` virtual ranks and receives the others' tiles
     with point-to-point transfers; the frame is the single-rank frame."""

@@ -145,15 +145,18 @@ def main():
         tdist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, rays_ms = dev.timing_history(args.steps)
-    local_rays = dev.stats().rays
+    local_rays = dev.stats().rays  # of this rank's last launch (with a larger share rank 0 launches several per frame)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    rays = torch.tensor([local_rays], dtype=torch.float64, device="cuda")
     if world > 1:
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-        tdist.all_reduce(rays, op=tdist.ReduceOp.SUM)
     elapsed = float(t.item())
-    frame_rays = float(rays.item())
+    # rays of one frame: counted once, outside the timed region, by a whole-frame launch (every
+    # frame of a fixed scene traces the same rays, however its tiles are dealt)
+    frame_rays = float(local_rays)
+    if world > 1:
+        dev.render_device(handle, camera, want_rgb=False)
+        frame_rays = float(dev.stats().rays)
 
     if rank == 0:
         avg_kernel_ms = sum(kernel_ms) / max(1, len(kernel_ms))
@@ -202,7 +205,7 @@ def main():
                 "flops_per_ray": fpr,
                 "rays_per_launch": int(local_rays),
                 "kernel_ms": avg_rays_ms,
-                "framebuffer_store_GBps": (camera.width * camera.height * 16 / world) / (avg_kernel_ms * 1e-3) / 1e9
+                "framebuffer_store_GBps": (camera.width * camera.height * 16 / (world - 1 + root_share)) / (avg_kernel_ms * 1e-3) / 1e9
                 if avg_kernel_ms > 0 else None,  # sanity counter: 12 B FP32 RGB + 4 B RGBA8 per pixel, written once
                 "all_kernels_ms": avg_kernel_ms,
                 "measured_valu_busy": measured.get("valu_busy"),

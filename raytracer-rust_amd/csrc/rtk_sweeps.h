@@ -91,7 +91,10 @@ __device__ __forceinline__ void sweep_primary(const DevScene& S, const float4* _
 template <int NR, bool WIDE, typename ExactFn, typename DoneFn>
 __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, float px, float py, float pz,
                                              const float (&gx)[NR], const float (&gy)[NR], const float (&gz)[NR],
-                                             const float (&rho)[NR], float thr, ExactFn&& exact, DoneFn&& done) {
+                                             const float (&rho)[NR], float thr, ExactFn&& exact, DoneFn&& done,
+                                             bool forward = false) {
+  // forward: only hits at positive ray parameters matter to the caller (NR == 1, rho == 0): a
+  // cluster that lies entirely behind the origin is not opened
   bool wave_live = __any(active);
   const bool cull = thr > -1.0e38f;  // rays of lights with w outside [0, 1] look at every sphere
   float lrho[NR];
@@ -117,7 +120,9 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
         const float d2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
         const float t = fmaxf(cl.w - s, 0.0f) * (1.0f + 8.0f * kEps32);
         const float rr = __builtin_fmaf(t, S.r_max * lrho[r], room) * (1.0f + 4.0f * kEps32);
-        pass |= rr >= 0.0f && __builtin_fmaf(rr, rr, -d2) >= 0.0f;
+        // s = (p - C).g: beyond room, every point of the ball has a negative ray parameter
+        const bool behind = forward && s > room;
+        pass |= !behind && rr >= 0.0f && __builtin_fmaf(rr, rr, -d2) >= 0.0f;
       }
       reach = active && pass;
     }
@@ -326,7 +331,8 @@ __device__ __forceinline__ void closest_general(const DevScene& S, bool active, 
   };
   auto done = [&]() { return false; };
   bool live = active;
-  sweep_filter<1, WIDE>(S, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done);
+  // hits behind the origin only matter for the refractive index n1 (the entry before the winner)
+  sweep_filter<1, WIDE>(S, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done, !track);
 }
 
 // Closest hit of a camera ray (unit direction, shared origin).

@@ -262,6 +262,23 @@ def ray_reaches_cluster(fs, p, G, omega, clusters):
     return (rr >= 0) & (fma(rr, rr, -d2) >= 0)
 
 
+def ray_cluster_behind(fs, p, G, clusters):
+    """`forward` part of sweep_filter's cluster test for plain rays (growth 0): True where the
+    cluster ball lies entirely behind the origin, so none of its spheres has a positive root;
+    -> [rays, clusters]."""
+    p = np.asarray(p, np.float64)
+    G = np.asarray(G, np.float64)
+    inv = 1.0 / np.sqrt((G * G).sum(axis=1))
+    g = (G * inv[:, None]).astype(F)
+    pc = (p - fs.center).astype(F)
+    pad = (F(16.0) * EPS32 * (np.abs(pc[:, 0]) + np.abs(pc[:, 1]) + np.abs(pc[:, 2]) + fs.c_max)).astype(F)
+    cl = clusters[None, :, :]
+    ux, uy, uz = (pc[:, None, 0] - cl[..., 0]).astype(F), (pc[:, None, 1] - cl[..., 1]).astype(F), (pc[:, None, 2] - cl[..., 2]).astype(F)
+    room = (cl[..., 3] + pad[:, None]).astype(F)
+    s = fma(uz, g[:, None, 2], fma(uy, g[:, None, 1], (ux * g[:, None, 0]).astype(F)))
+    return s > room
+
+
 def camera_ray_reaches_cluster(directions, records):
     """Cluster test of sweep_primary: unit FP32 directions [n, 3] against camera-side cluster
     records {L, Rs} [m, 4]; -> [n, m]."""

@@ -311,6 +311,44 @@ def test_per_ray_cluster_test_keeps_every_grazing_hit(scale, light_w):
     assert light_w < 1.0 or scale < 50 or reach.mean() < 0.5
 
 
+@pytest.mark.parametrize("scale", [2.0, 50.0, 400.0, 3000.0])
+def test_clusters_behind_the_origin_hold_no_positive_root(scale):
+    """Closest-hit rays skip a cluster whose ball lies entirely behind the ray origin.  Adversarial
+    spheres: centred behind the origin with the origin just inside their front surface, so their
+    larger root is a tiny positive number; none of them may sit in a skipped cluster."""
+    from filter_model import ray_cluster_behind
+
+    rng = np.random.default_rng(int(scale) + 77)
+    n = 1500
+    p = rng.normal(size=(n, 3)) * scale * 0.4
+    d = _unit(rng.normal(size=(n, 3))) * rng.uniform(0.2, 3.0, size=(n, 1))  # secondary rays are not unit
+    back = rng.uniform(0.01, 4.0, size=(n, 1))
+    c = p - _unit(d) * back + rng.normal(size=(n, 3)) * back * rng.uniform(0.0, 0.5, size=(n, 1))
+    dist = np.sqrt(((p - c) ** 2).sum(axis=1))
+    for delta in (1e-13, 1e-9, 1e-6, 1e-3):
+        R = dist * (1.0 + delta)  # the origin is inside by delta: roots straddle zero
+        oo, dd = (p - c) / R[:, None], d / R[:, None]
+        a, b, cc = (dd * dd).sum(axis=1), 2.0 * (oo * dd).sum(axis=1), (oo * oo).sum(axis=1) - 1.0
+        disc = b * b - 4.0 * a * cc
+        t1 = (-b + np.sqrt(np.maximum(disc, 0.0))) / (2.0 * a)
+        positive = (disc >= 0) & (t1 > 0.0)
+        assert positive.mean() > 0.9
+        cc3, RR = _random_clusters_around(rng, c, R)
+        fs = FilterScene(cc3.reshape(-1, 3), RR.reshape(-1))
+        balls = sphere_balls(fs)
+        clusters = cluster_balls(balls[:, :3], balls[:, 3], bundle=cc3.shape[1])  # cluster i holds sphere i first
+        behind = ray_cluster_behind(fs, p, d, clusters)
+        own = behind[np.arange(n), np.arange(n)]
+        assert not (positive & own).any(), f"skipped {int((positive & own).sum())} spheres with a positive root at delta={delta}"
+    # not vacuous: clusters well behind are skipped
+    far = p - _unit(d) * (20.0 + scale)
+    cc3, RR = _random_clusters_around(rng, far, np.full(n, 0.5))
+    fs = FilterScene(cc3.reshape(-1, 3), RR.reshape(-1))
+    balls = sphere_balls(fs)
+    clusters = cluster_balls(balls[:, :3], balls[:, 3], bundle=cc3.shape[1])
+    assert ray_cluster_behind(fs, p, d, clusters)[np.arange(n), np.arange(n)].mean() > 0.9
+
+
 @pytest.mark.parametrize("scale", [3.0, 60.0, 1500.0])
 def test_camera_ray_cluster_test_keeps_every_grazing_hit(scale):
     rng = np.random.default_rng(int(scale) + 31)

@@ -522,3 +522,26 @@ def test_resolve_of_special_values(rtk, dev):
     assert tuple(rgba[0, 0]) == (255, 255, 255, 255) and tuple(rgba[0, 1]) == (0, 0, 0, 255)
     assert tuple(rgba[0, 2]) == (0, 0, 0, 255) and tuple(rgba[1, 0]) == (159, 0, 0, 255)
     assert float(rgb[1, 0, 0]) == 0.625 and bool(torch.isnan(rgb[0, 2]).all())
+
+
+def test_largest_configuration_crops(rtk, dev, oracle):
+    """C5 at its full 16384 x 16384 (268 M pixels, 8 lights): the frame stays on the device, two
+    rectangles of it are checked against the oracle, and the ray count respects its bounds."""
+    import torch
+
+    scene, camera = rtk.synthetic.config("C5")
+    assert (camera.width, camera.height) == (16384, 16384) and len(scene.lights) == 8
+    h = dev.upload(scene)
+    rgb, rgba = dev.render_device(h, camera)
+    st = dev.stats()
+    assert st.rays_primary == 16384 * 16384 and st.rays_secondary == 0
+    assert st.rays_primary <= st.rays <= st.rays_primary * 9
+    for rect in [(8128, 9000, 8256, 9096), (16256, 16300, 16384, 16384)]:
+        x0, y0, x1, y1 = rect
+        want_rgb, want_rgba, _ = oracle.render(scene, camera, rect=rect, threads=16)
+        g_rgb, g_rgba = rgb[y0:y1, x0:x1].cpu().numpy(), rgba[y0:y1, x0:x1].cpu().numpy()
+        max_rel, _, _, not_equal = assert_parity(g_rgb, g_rgba, want_rgb, want_rgba, f"C5 crop {rect}")
+        assert not_equal == 0 and max_rel < 1e-6
+    del rgb, rgba
+    torch.cuda.empty_cache()
+    h.release()

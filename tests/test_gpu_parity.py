@@ -545,3 +545,14 @@ def test_largest_configuration_crops(rtk, dev, oracle):
     del rgb, rgba
     torch.cuda.empty_cache()
     h.release()
+
+
+def test_the_largest_light_count(rtk, dev, oracle):
+    """64 lights, the most the library takes: sixteen batches of four, both with scene-file lights
+    (w = 0) and with lights built from points (w = 1)."""
+    for w in (0.0, 1.0):
+        scene = rtk.synthetic.make_scene(30, True, 64, 4321)
+        scene.lights = [rtk.PointLight(rtk.vec4(*l.position[:3], w), l.intensity) for l in scene.lights]
+        camera = rtk.synthetic.make_camera(30, 160, 90)
+        canvas = check_against_oracle(dev, oracle, scene, camera, f"64 lights, w = {w}")
+        assert canvas.stats.rays_shadow <= 64 * canvas.stats.rays_primary

@@ -44,16 +44,57 @@ struct StackEntry {
 // Scenes of a handful of objects (the reference's bundled scene has three): every object is
 // intersected exactly, in object order; no filter records, no clusters.
 constexpr uint32_t kBruteObjects = 8;
-__device__ __forceinline__ void closest_brute(const DevScene& S, bool active, V3 o, V3 d, Closest& best) {
+template <bool TRACK>
+__device__ __forceinline__ void closest_brute(const DevScene& S, bool active, V3 o, V3 d, Closest& best, bool& graze) {
   closest_init(best);
-  const bool track = S.track_n1 != 0;
+  constexpr bool track = TRACK;
   if (!active) return;
   for (uint32_t obj = 0; obj < S.n_objects; ++obj) {
     double t0, t1;
     const int n = intersect_object(S.objects[obj], o, d, 0.0, t0, t1);
     if (n >= 1) closest_consider(best, t0, obj, track);
     if (n == 2) closest_consider(best, t1, obj, track);
+    if (n == 2 && track && fabs(t0 - t1) < 0.00001) graze = true;
   }
+}
+
+// n1 of `LightingData::compute_refractivity` (src/scene/lighting.rs:81-116) by the letter, for the
+// rays whose hit list holds a sphere with both roots within 1e-5 of each other.  The reference
+// walks the sorted list (stable: ties in object order, a sphere's smaller root first) up to the
+// first entry that `Hit::eq` (same object, distances within 1e-5: src/scene.rs:354-364) calls the
+// winner -- the winner itself, or the same sphere's other root just before it -- and keeps a list
+// of "containers": every entry is pushed, except that an entry equal to one already there removes
+// it and stays out, which only the two close roots of one sphere can do to each other.  n1 is the
+// refractive index of the last container at that point, 1.0 without one.  (n2 is always the
+// winner's own index: nothing before the stopping entry equals it.)  Every object is intersected
+// again, exactly; this runs for a handful of rays per frame at most.
+__device__ __forceinline__ double literal_n1(const DevScene& S, V3 o, V3 d, uint32_t own, double t_win) {
+  double b_t = t_win;
+  uint32_t b_root = 0;
+  {
+    double t0, t1;
+    const int n = intersect_object(S.objects[own], o, d, 0.0, t0, t1);
+    if (n == 2 && t_win != t0) {  // the winner is the larger root
+      b_root = 1;
+      if (fabs(t0 - t1) < 0.00001) b_t = t0, b_root = 0;  // ... and its sibling already counts as the winner
+    }
+  }
+  double last_t = -DBL_MAX;
+  uint32_t last_obj = 0xffffffffu, last_root = 0;
+  for (uint32_t obj = 0; obj < S.n_objects; ++obj) {
+    double t[2];
+    const int n = intersect_object(S.objects[obj], o, d, 0.0, t[0], t[1]);
+    if (n == 0) continue;
+    bool before[2] = {false, false};
+    for (int r = 0; r < n; ++r)
+      before[r] = t[r] < b_t || (t[r] == b_t && (obj < own || (obj == own && (uint32_t)r < b_root)));
+    if (n == 2 && before[0] && before[1] && fabs(t[0] - t[1]) < 0.00001) continue;  // the second root removes the first
+    for (int r = 0; r < n; ++r)
+      if (before[r] && (last_obj == 0xffffffffu || t[r] > last_t ||
+                        (t[r] == last_t && (obj > last_obj || (obj == last_obj && (uint32_t)r > last_root)))))
+        last_t = t[r], last_obj = obj, last_root = (uint32_t)r;
+  }
+  return last_obj == 0xffffffffu ? 1.0 : S.objects[last_obj].refractivity;
 }
 // `Scene::is_shadowed` (src/scene.rs:208-225): one shadow ray per light until one is blocked.
 __device__ __forceinline__ bool shadow_brute(const DevScene& S, bool active, V3 p, unsigned& n_rays) {
@@ -75,7 +116,7 @@ __device__ __forceinline__ bool shadow_brute(const DevScene& S, bool active, V3 
   return false;
 }
 
-template <bool SECONDARY, bool PRIMARY_FILTER, int LB, bool WIDE, bool BRUTE = false>
+template <bool SECONDARY, bool PRIMARY_FILTER, int LB, bool WIDE, bool BRUTE, bool TRACK>
 __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restrict__ prim,
                                         const float4* __restrict__ prim_cluster, bool valid, V3 o,
                                         V3 d, unsigned& c_primary, unsigned& c_shadow, unsigned& c_secondary,
@@ -117,12 +158,13 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
         ++c_secondary;
     }
     Closest best;
+    bool graze = false;  // some sphere has both roots within 1e-5 of each other on this ray
     if (BRUTE)
-      closest_brute(S, have, ro, rd, best);
+      closest_brute<TRACK>(S, have, ro, rd, best, graze);
     else if (PRIMARY_FILTER && (!SECONDARY || iter == 0))
-      closest_primary(S, prim, prim_cluster, have, ro, rd, best, c_exact);
+      closest_primary<TRACK>(S, prim, prim_cluster, have, ro, rd, best, c_exact, graze);
     else
-      closest_general<WIDE>(S, have, ro, rd, best, c_exact);
+      closest_general<WIDE, TRACK>(S, have, ro, rd, best, c_exact, graze);
 
     const bool hit = have && best.obj != 0xffffffffu;
     if (have && !hit) color = color + scene_ambient * weight;  // trace_inner: miss -> ambient_color
@@ -146,8 +188,14 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
           double n2 = ob.refractivity;
           // n1: material of the entry just before the hit in the sorted list, else 1.0.  When
           // every refractivity in the scene is 1.0 (track_n1 == 0) that is 1.0 either way.
+          // Two roots that close make the reference's container list drop entries: then by the letter.
           double n1 = 1.0;
-          if (S.track_n1 && best.prev_obj != 0xffffffffu) n1 = S.objects[best.prev_obj].refractivity;
+          if constexpr (TRACK) {
+            if (graze)
+              n1 = literal_n1(S, ro, rd, obj, best.t);
+            else if (best.prev_obj != 0xffffffffu)
+              n1 = S.objects[best.prev_obj].refractivity;
+          }
           const double cos_i = dot3(eye, normal);
           double w_refl = weight * reflectivity, w_refr = weight * transparency;
           if (reflectivity > 0.0 && transparency > 0.0) {
@@ -205,7 +253,7 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
 // `Camera::render` (src/scene/cameras.rs:72-85): ray generation (cameras.rs:52-69 with the
 // matrix inverse hoisted to the host), trace, and the framebuffer store
 // (src/graphics.rs:44-46, 59-74).
-template <bool SECONDARY, int LB, bool WIDE, bool BRUTE = false>
+template <bool SECONDARY, int LB, bool WIDE, bool BRUTE, bool TRACK>
 __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                         const float4* __restrict__ prim_cluster, RenderTarget T,
                                                         DevCounters* counters) {
@@ -224,7 +272,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera
   const V3 dir = camera_ray_direction(C, x, y);  // cameras.rs:52-69
 
   unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
-  V3 color = trace_ray<SECONDARY, true, LB, WIDE, BRUTE>(S, prim, prim_cluster, valid, origin, dir, c_primary, c_shadow, c_secondary, c_exact);
+  V3 color = trace_ray<SECONDARY, true, LB, WIDE, BRUTE, TRACK>(S, prim, prim_cluster, valid, origin, dir, c_primary, c_shadow, c_secondary, c_exact);
 
   // ---- framebuffer store, transposed through LDS so that every wavefront writes whole
   // 128-byte (RGBA8) / 384-byte (FP32 RGB) tile rows
@@ -276,7 +324,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera
 }
 
 // `Scene::trace` for caller-supplied rays (src/scene.rs:136-138): n x 4 doubles each.
-template <int LB, bool WIDE>
+template <int LB, bool WIDE, bool TRACK>
 __global__ void __launch_bounds__(kBlock) trace_rays_kernel(DevScene S, const double* __restrict__ origins,
                                                             const double* __restrict__ directions, uint64_t n,
                                                             double* __restrict__ colors, DevCounters* counters) {
@@ -288,7 +336,7 @@ __global__ void __launch_bounds__(kBlock) trace_rays_kernel(DevScene S, const do
     d = ld3(directions + 4 * i);
   }
   unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
-  V3 color = trace_ray<true, false, LB, WIDE>(S, nullptr, nullptr, valid, o, d, c_primary, c_shadow, c_secondary, c_exact);
+  V3 color = trace_ray<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, valid, o, d, c_primary, c_shadow, c_secondary, c_exact);
   if (valid) {
     colors[3 * i + 0] = color.x;
     colors[3 * i + 1] = color.y;
@@ -459,15 +507,15 @@ __global__ void __launch_bounds__(kBlock) untile_sampled_kernel(uint32_t width, 
 // spheres never take it.
 constexpr uint32_t kWideScene = 256;
 
-template <bool WIDE>
+template <bool WIDE, bool TRACK>
 static hipError_t launch_render_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, const DevCamera& C,
                                    const float4* prim, const float4* prim_cluster, const RenderTarget& T,
                                    DevCounters* counters) {
   switch (lb) {
-    case 1: hipLaunchKernelGGL((render_kernel<true, 1, WIDE>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
-    case 2: hipLaunchKernelGGL((render_kernel<true, 2, WIDE>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
-    case 4: hipLaunchKernelGGL((render_kernel<true, 4, WIDE>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
-    default: hipLaunchKernelGGL((render_kernel<true, 8, WIDE>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
+    case 1: hipLaunchKernelGGL((render_kernel<true, 1, WIDE, false, TRACK>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
+    case 2: hipLaunchKernelGGL((render_kernel<true, 2, WIDE, false, TRACK>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
+    case 4: hipLaunchKernelGGL((render_kernel<true, 4, WIDE, false, TRACK>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
+    default: hipLaunchKernelGGL((render_kernel<true, 8, WIDE, false, TRACK>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
   }
   return hipGetLastError();
 }
@@ -492,23 +540,32 @@ hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, 
                          const float4* prim_cluster, const RenderTarget& T, DevCounters* counters) {
   if (T.n_local_tiles == 0) return hipSuccess;
   dim3 grid(T.n_local_tiles);
+  // TRACK kernels (some refractive index differs from the others) carry the entry before the winner
+  // and the literal n1 evaluation; the others drop both
+  const bool track = S.track_n1 != 0;
   if (S.n_objects <= kBruteObjects) {
-    hipLaunchKernelGGL((render_kernel<true, 1, false, true>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters);
+    if (track)
+      hipLaunchKernelGGL((render_kernel<true, 1, false, true, true>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters);
+    else
+      hipLaunchKernelGGL((render_kernel<true, 1, false, true, false>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters);
     return hipGetLastError();
   }
   const int lb = light_batch_for(S.n_lights);
-  if (S.n_spheres >= kWideScene) return launch_render_lb<true>(lb, grid, st, S, C, prim, prim_cluster, T, counters);
-  return launch_render_lb<false>(lb, grid, st, S, C, prim, prim_cluster, T, counters);
+  if (S.n_spheres >= kWideScene)
+    return track ? launch_render_lb<true, true>(lb, grid, st, S, C, prim, prim_cluster, T, counters)
+                 : launch_render_lb<true, false>(lb, grid, st, S, C, prim, prim_cluster, T, counters);
+  return track ? launch_render_lb<false, true>(lb, grid, st, S, C, prim, prim_cluster, T, counters)
+               : launch_render_lb<false, false>(lb, grid, st, S, C, prim, prim_cluster, T, counters);
 }
 
-template <bool WIDE>
+template <bool WIDE, bool TRACK>
 static hipError_t launch_trace_rays_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, const double* origins,
                                        const double* directions, uint64_t n, double* colors, DevCounters* counters) {
   switch (lb) {
-    case 1: hipLaunchKernelGGL((trace_rays_kernel<1, WIDE>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
-    case 2: hipLaunchKernelGGL((trace_rays_kernel<2, WIDE>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
-    case 4: hipLaunchKernelGGL((trace_rays_kernel<4, WIDE>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
-    default: hipLaunchKernelGGL((trace_rays_kernel<8, WIDE>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
+    case 1: hipLaunchKernelGGL((trace_rays_kernel<1, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
+    case 2: hipLaunchKernelGGL((trace_rays_kernel<2, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
+    case 4: hipLaunchKernelGGL((trace_rays_kernel<4, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
+    default: hipLaunchKernelGGL((trace_rays_kernel<8, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, origins, directions, n, colors, counters); break;
   }
   return hipGetLastError();
 }
@@ -518,8 +575,12 @@ hipError_t launch_trace_rays(hipStream_t st, const DevScene& S, const double* or
   if (n == 0) return hipSuccess;
   dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
   const int lb = light_batch_for(S.n_lights);
-  if (S.n_spheres >= kWideScene) return launch_trace_rays_lb<true>(lb, grid, st, S, origins, directions, n, colors, counters);
-  return launch_trace_rays_lb<false>(lb, grid, st, S, origins, directions, n, colors, counters);
+  const bool track = S.track_n1 != 0;
+  if (S.n_spheres >= kWideScene)
+    return track ? launch_trace_rays_lb<true, true>(lb, grid, st, S, origins, directions, n, colors, counters)
+                 : launch_trace_rays_lb<true, false>(lb, grid, st, S, origins, directions, n, colors, counters);
+  return track ? launch_trace_rays_lb<false, true>(lb, grid, st, S, origins, directions, n, colors, counters)
+               : launch_trace_rays_lb<false, false>(lb, grid, st, S, origins, directions, n, colors, counters);
 }
 hipError_t launch_untile(hipStream_t st, uint32_t width, uint32_t height, uint32_t world, uint64_t rgb_stride_floats,
                          uint64_t px_stride_pixels, const float* rgb_c, float* rgb_f, const uint8_t* px_c, uint8_t* px_f) {

@@ -305,11 +305,12 @@ __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3
 // ------------------------------------------------------------------------------------
 // Closest hit of a general ray (origin o, direction d with w = 0, not necessarily unit):
 // `Scene::intersect` + `HitList::closest_hit` (src/scene.rs:156-169, 325-340).
-template <bool WIDE>
+// TRACK: the scene holds different refractive indices, so the entry before the winner (n1) matters.
+template <bool WIDE, bool TRACK>
 __device__ __forceinline__ void closest_general(const DevScene& S, bool active, V3 o, V3 d, Closest& best,
-                                                unsigned& n_exact) {
+                                                unsigned& n_exact, bool& graze) {
   closest_init(best);
-  const bool track = S.track_n1 != 0;
+  constexpr bool track = TRACK;
   if (active) {
     for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
       uint32_t obj = S.plane_object[ip];
@@ -327,6 +328,7 @@ __device__ __forceinline__ void closest_general(const DevScene& S, bool active, 
     if (intersect_object(S.objects[obj], o, d, 0.0, t0, t1)) {
       closest_consider(best, t0, obj, track);
       closest_consider(best, t1, obj, track);
+      if (track && fabs(t0 - t1) < 0.00001) graze = true;  // `Hit::eq` would call the two roots one hit
     }
   };
   auto done = [&]() { return false; };
@@ -336,11 +338,12 @@ __device__ __forceinline__ void closest_general(const DevScene& S, bool active, 
 }
 
 // Closest hit of a camera ray (unit direction, shared origin).
+template <bool TRACK>
 __device__ __forceinline__ void closest_primary(const DevScene& S, const float4* __restrict__ prim,
                                                 const float4* __restrict__ prim_cluster, bool active, V3 o, V3 d,
-                                                Closest& best, unsigned& n_exact) {
+                                                Closest& best, unsigned& n_exact, bool& graze) {
   closest_init(best);
-  const bool track = S.track_n1 != 0;
+  constexpr bool track = TRACK;
   if (active) {
     for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
       uint32_t obj = S.plane_object[ip];
@@ -354,6 +357,7 @@ __device__ __forceinline__ void closest_primary(const DevScene& S, const float4*
     if (intersect_object(S.objects[obj], o, d, 0.0, t0, t1)) {
       closest_consider(best, t0, obj, track);
       closest_consider(best, t1, obj, track);
+      if (track && fabs(t0 - t1) < 0.00001) graze = true;
     }
   };
   sweep_primary(S, prim, prim_cluster, active, (float)d.x, (float)d.y, (float)d.z, exact);

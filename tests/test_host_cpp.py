@@ -218,3 +218,53 @@ def test_command_line_renderer_with_samples(rtk, host_bin, golden_dir, tmp_path)
     r = subprocess.run([os.path.join(host_bin, "rtk_render"), scene_file, str(out), "--samples", "0"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "samples_per_axis" in r.stderr
+
+
+def _build_c_example(tmp_path):
+    exe = str(tmp_path / "minimal")
+    lib_dir = os.path.join(ROOT, "raytracer-rust_amd", "csrc")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "minimal.c"), "-L" + lib_dir, "-lrtk", "-lm",
+                        "-Wl,-rpath," + lib_dir, "-o", exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_c_example_compiles_as_c99_and_fails_loudly_without_a_gpu(rtk, tmp_path):
+    """include/rtk.h is a C header: a C99 program with no host library builds against it."""
+    import importlib
+
+    import torch
+
+    device = importlib.import_module("raytracer-rust_amd.device")
+    if not os.path.exists(device.LIB_PATH):
+        device.build_library()
+    exe = _build_c_example(tmp_path)
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, str(tmp_path / "x.ppm")], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and "no HIP device" in r.stderr and not os.path.exists(tmp_path / "x.ppm")
+
+
+@pytest.mark.gpu
+def test_c_example_renders_what_the_python_host_renders(rtk, tmp_path):
+    import importlib
+
+    exe = _build_c_example(tmp_path)
+    out = tmp_path / "minimal.ppm"
+    r = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    data = open(out, "rb").read()
+    header = b"P6\n640 360\n255\n"
+    assert data.startswith(header)
+    pixels = np.frombuffer(data[len(header):], dtype=np.uint8).reshape(360, 640, 3)
+    scene = rtk.Scene()
+    scene.add_light(rtk.PointLight(rtk.vec3(-10, 10, -10), rtk.WHITE))
+    scene.add_object(rtk.Plane(rtk.vec3(0, 1, 0)).with_material(
+        rtk.Material.default().with_pattern(rtk.Texture.checker(rtk.WHITE, rtk.BLACK)).with_specular(0.0)))
+    scene.add_object(rtk.Sphere().with_transform(rtk.Matrix4x4.translate(0, 1, 0)).with_material(
+        rtk.Material.default().with_color(rtk.rgb(1.0, 0.2, 0.2))))
+    dev = importlib.import_module("raytracer-rust_amd.device").Device(0)
+    canvas = rtk.Camera(640, 360, rtk.PI / 3.0).render(scene, dev)
+    dev.close()
+    assert (pixels == canvas.rgba8[..., :3]).all()
+    assert f"{canvas.stats.rays} rays" in r.stdout

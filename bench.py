@@ -227,10 +227,14 @@ def main():
         }
         if world == 1 and not args.no_extra:
             extra = {}
-            for name in ("C2", "C3"):
+            for name in ("C1", "C2", "C3"):
                 if name == args.workload:
                     continue
-                s2, c2 = rtk.synthetic.config(name)
+                if name == "C1":  # the reference's bundled scene at its own resolution (src/main.rs:17-20)
+                    s2 = rtk.PackedScene.from_yaml_file(os.path.join(ROOT, "tests", "golden", "test01.yaml")).build()
+                    c2 = rtk.Camera(1920, 1080, rtk.PI / 3.0)
+                else:
+                    s2, c2 = rtk.synthetic.config(name)
                 h2 = dev.upload(s2)
                 f2, _, _ = flops_per_ray(s2, rtk)
                 best = None

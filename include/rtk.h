@@ -121,6 +121,8 @@ typedef struct rtk_stats {
   double rays_ms;       /* ... of the ray kernels alone (camera + shadow + secondary rays); equals kernel_ms
                            when rays and shading run in one kernel (scenes with reflective or
                            transparent materials, rtk_trace_rays) */
+  double gather_ms;     /* rtk_group_get_stats only: HIP-event time of the last frame's exchange on the root
+                           device (first receive posted .. last band landed); 0 elsewhere */
 } rtk_stats;
 
 /* Which tiles of the frame a call renders.  Tiles are RTK_TILE_W x RTK_TILE_H pixels,
@@ -135,6 +137,26 @@ typedef struct rtk_tiling {
   uint32_t world;
 } rtk_tiling;
 
+/* The other partition: whole tile rows.  The tile rows [first_tile_row, first_tile_row +
+ * n_tile_rows) of the frame are cut into bands of band_tile_rows tile rows (8 * band_tile_rows
+ * pixel rows; the last band may be shorter), and band b goes to rank b % world.  A rank's
+ * pixels are then whole rows of the frame: contiguous runs of the final row-major image, so a
+ * receiver can land them in place and nothing has to be de-interleaved (pixels are
+ * independent, src/scene/cameras.rs:75-82, so any partition renders the same frame).
+ *  compact == 0: the outputs are whole W x H frames; the call writes only its own rows, at
+ *                their final place.
+ *  compact == 1: the outputs hold only this rank's tile rows, one after the other in
+ *                ascending order, row-major at the frame's width: rtk_band_pixel_rows()
+ *                rows (8 per tile row; rows of the last tile row that lie below the frame
+ *                are not written). */
+typedef struct rtk_banding {
+  uint32_t rank, world;
+  uint32_t band_tile_rows; /* >= 1 */
+  uint32_t first_tile_row;
+  uint32_t n_tile_rows;    /* 0: down to the bottom of the frame */
+  uint32_t compact;
+} rtk_banding;
+
 typedef struct rtk_context rtk_context;           /* opaque: one HIP device, stream, scratch */
 typedef struct rtk_scene_handle rtk_scene_handle; /* opaque: a scene resident in HBM        */
 
@@ -146,6 +168,11 @@ int rtk_camera_init(rtk_camera* camera, uint32_t width, uint32_t height, double 
 /* Number of tiles a rank owns, and the number of pixels of its compact buffer. */
 uint64_t rtk_tiles_for_rank(uint32_t width, uint32_t height, uint32_t rank, uint32_t world);
 uint64_t rtk_compact_pixels(uint32_t width, uint32_t height, uint32_t rank, uint32_t world);
+
+/* Tile rows a rank owns under a band partition (0 for a bad partition), and the pixel rows of
+ * its compact buffer (8 per tile row). */
+uint64_t rtk_band_tile_rows(uint32_t height, const rtk_banding* banding);
+uint64_t rtk_band_pixel_rows(uint32_t height, const rtk_banding* banding);
 
 /* Binds a context to HIP device `device_id`.  Fails with RTK_ERR_NO_DEVICE when the
  * device is absent or is not gfx950. */
@@ -171,8 +198,10 @@ void rtk_scene_release(rtk_context* ctx, rtk_scene_handle* scene);
  *              saturation at 0 and 255, NaN -> 0; may be NULL.
  *  tiling    : NULL means {0, 1}.  With world > 1 both outputs use the compact layout
  *              described at rtk_tiling and hold rtk_compact_pixels() pixels.
- *  hip_stream: a hipStream_t, or NULL for the context's own stream.  The call is
- *              asynchronous on that stream.
+ *  hip_stream: a hipStream_t, or NULL for the context's own stream (which is not ordered
+ *              with HIP's default stream).  The call is asynchronous on that stream.  Render calls of one context share per-camera
+ *              records and counters; the library orders them: a call on another stream than
+ *              the previous call's first waits (on the device) for that call to finish.
  * Precision: object sweeps run a conservative FP32 filter; every candidate the filter
  * keeps, and all shading, is evaluated in f64 with the reference's formulas, so the
  * colour differs from an f64 render only by FMA contraction and summation order before
@@ -181,8 +210,13 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
                       const rtk_tiling* tiling, float* d_rgb_f32, uint8_t* d_rgba8,
                       void* hip_stream);
 
+/* rtk_render_device for one rank of a band partition (see rtk_banding).  One sample per pixel. */
+int rtk_render_device_bands(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera,
+                            const rtk_banding* banding, float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream);
+
 /* Same render with HOST output buffers (whole frame, row-major); uploads the scene,
- * renders, copies back and synchronises.  stats may be NULL. */
+ * renders, copies back and synchronises.  stats may be NULL.  The frame is rendered in
+ * horizontal blocks and each block travels to the host while the next one renders. */
 int rtk_render(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camera,
                float* rgb_f32_out, uint8_t* rgba8_out, rtk_stats* stats);
 

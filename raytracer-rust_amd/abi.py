@@ -97,6 +97,7 @@ class rtk_stats(C.Structure):
         ("exact_tests", C.c_uint64),
         ("kernel_ms", C.c_double),
         ("rays_ms", C.c_double),
+        ("gather_ms", C.c_double),
     ]
 
     @property
@@ -106,6 +107,17 @@ class rtk_stats(C.Structure):
 
 class rtk_tiling(C.Structure):
     _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32)]
+
+
+class rtk_banding(C.Structure):
+    _fields_ = [
+        ("rank", C.c_uint32),
+        ("world", C.c_uint32),
+        ("band_tile_rows", C.c_uint32),
+        ("first_tile_row", C.c_uint32),
+        ("n_tile_rows", C.c_uint32),
+        ("compact", C.c_uint32),
+    ]
 
 
 # Every symbol include/rtk.h declares: name -> (restype, argtypes).
@@ -120,6 +132,12 @@ SYMBOLS = {
     "rtk_render_device": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.POINTER(rtk_camera), C.POINTER(rtk_tiling), C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "rtk_band_tile_rows": (C.c_uint64, [C.c_uint32, C.POINTER(rtk_banding)]),
+    "rtk_band_pixel_rows": (C.c_uint64, [C.c_uint32, C.POINTER(rtk_banding)]),
+    "rtk_render_device_bands": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.POINTER(rtk_camera), C.POINTER(rtk_banding), C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "rtk_render": (
         C.c_int,

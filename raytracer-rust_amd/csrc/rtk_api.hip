@@ -4,9 +4,7 @@
 // There is no CPU rendering path in this library: every entry point that produces pixels
 // launches the gfx950 kernels and fails with an error code when no device is usable.
 
-#include "../../include/rtk.h"
-#include "rtk_device.h"
-#include "rtk_kernels.h"
+#include "rtk_internal.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -20,10 +18,15 @@
 #include <utility>
 #include <vector>
 
+// The f64 matrix code below (cofactor inverse, look_at) must round like the reference's: no
+// fused multiply-adds, whatever the host architecture or -march offers.
+#pragma clang fp contract(off)
+
 namespace {
-
 thread_local std::string g_error;
+}
 
+namespace rtk {
 int fail(int code, const std::string& msg) {
   g_error = msg;
   return code;
@@ -32,11 +35,12 @@ int fail_hip(hipError_t e, const char* what) {
   g_error = std::string(what) + ": " + hipGetErrorString(e);
   return RTK_ERR_HIP;
 }
-#define RTK_HIP(call)                                   \
-  do {                                                  \
-    hipError_t e_ = (call);                             \
-    if (e_ != hipSuccess) return fail_hip(e_, #call);   \
-  } while (0)
+}  // namespace rtk
+
+using rtk::fail;
+using rtk::fail_hip;
+
+namespace {
 
 // ---------------------------------------------------------------- f64 matrix helpers
 // Row-major 4x4, element (row, col) at [col + 4*row] (src/maths/matrices.rs:69-71).
@@ -140,50 +144,6 @@ uint32_t round_up_to(uint32_t n, uint32_t m) { return (n + m - 1) / m * m; }
 
 }  // namespace
 
-// ---------------------------------------------------------------- opaque handles
-struct rtk_scene_handle {
-  rtk::DevScene dev{};
-  void* d_block = nullptr;  // the one device allocation every pointer below points into
-  void* d_objects = nullptr;
-  void* d_lights = nullptr;
-  void* d_filter = nullptr;
-  void* d_exact = nullptr;
-  void* d_sph_object = nullptr;
-  void* d_plane_object = nullptr;
-  void* d_light_kind = nullptr;
-  void* d_pattern_inv = nullptr;
-  float4* d_prim = nullptr;  // primary-ray filter records (rebuilt per camera)
-  float4* d_prim_ball = nullptr;  // camera-ray records of the wavefront-level cone test (rebuilt per camera)
-  void* d_sph_ball = nullptr;
-  void* d_cluster_ball = nullptr;
-  float4* d_prim_cluster = nullptr;  // camera-ray records of the cluster balls (rebuilt per camera)
-  void* d_light_filter = nullptr;
-  void* d_k_table = nullptr;
-  void* d_sph_tab = nullptr;
-};
-
-struct rtk_context {
-  int device = -1;
-  hipStream_t stream = nullptr;
-  // One (start, end of the ray kernels, stop) event triple per recent call, used round-robin, so
-  // that a caller can render many frames back to back and read their kernel times afterwards.
-  hipEvent_t ev_start[RTK_TIMING_HISTORY] = {}, ev_rays[RTK_TIMING_HISTORY] = {}, ev_stop[RTK_TIMING_HISTORY] = {};
-  bool ev_split[RTK_TIMING_HISTORY] = {};  // ev_rays was recorded by the call that used the slot
-  uint64_t n_timed = 0;                    // calls that recorded a triple; the newest sits in slot (n_timed - 1) % N
-  rtk::DevCounters* d_counters = nullptr;
-  hipStream_t last_stream = nullptr;
-  // staging for rtk_render (host-buffer variant)
-  float* d_rgb = nullptr;
-  uint8_t* d_rgba8 = nullptr;
-  size_t cap_pixels = 0;
-  // intermediate records of the three-kernel path (grown on demand, kept for the next frame)
-  rtk::OpaqueBuffers opaque{};
-  size_t cap_opaque = 0;
-  // sample frame of rtk_render_device_sampled (grown on demand)
-  float* d_samples = nullptr;
-  size_t cap_samples = 0;  // in samples
-};
-
 extern "C" {
 
 const char* rtk_last_error(void) { return g_error.c_str(); }
@@ -250,12 +210,14 @@ uint64_t rtk_compact_pixels(uint32_t width, uint32_t height, uint32_t rank, uint
 }
 
 static hipError_t create_timing_events(rtk_context* ctx) {
+  hipError_t e;
   for (int i = 0; i < RTK_TIMING_HISTORY; ++i) {
-    hipError_t e;
     if ((e = hipEventCreate(&ctx->ev_start[i])) != hipSuccess || (e = hipEventCreate(&ctx->ev_rays[i])) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev_stop[i])) != hipSuccess)
       return e;
   }
+  for (int i = 0; i < rtk_context::kHostBlocks; ++i)
+    if ((e = hipEventCreateWithFlags(&ctx->ev_block[i], hipEventDisableTiming)) != hipSuccess) return e;
   return hipSuccess;
 }
 
@@ -275,6 +237,7 @@ int rtk_create(int device_id, rtk_context** out) {
   if (!ctx) return fail(RTK_ERR_NOMEM, "rtk_create: out of host memory");
   ctx->device = device_id;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = create_timing_events(ctx)) != hipSuccess ||
       (e = hipMalloc((void**)&ctx->d_counters, sizeof(rtk::DevCounters) * rtk::kCounterShards)) != hipSuccess ||
       (e = hipMemset(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards)) != hipSuccess) {
@@ -289,6 +252,7 @@ void rtk_destroy(rtk_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
   if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -301,6 +265,9 @@ void rtk_destroy(rtk_context* ctx) {
     if (ctx->ev_rays[i]) (void)hipEventDestroy(ctx->ev_rays[i]);
     if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
   }
+  for (hipEvent_t ev : ctx->ev_block)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -350,14 +317,23 @@ static void cluster_order(std::vector<double4>& exact, std::vector<uint32_t>& ob
   object.swap(o2);
 }
 
-static int scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle** out);
+static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& out);
 
 int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle** out) {
   if (!ctx || !scene || !out) return fail(RTK_ERR_INVALID, "rtk_scene_upload: null argument");
   *out = nullptr;
+  rtk::FlatScene flat;
+  const int rc = rtk::flatten_scene(scene, flat);
+  if (rc != RTK_OK) return rc;
+  return rtk::place_scene(ctx, flat, out);
+}
+
+}  // extern "C"
+
+int rtk::flatten_scene(const rtk_scene* scene, rtk::FlatScene& out) {
   // the host-side record arrays are std::vectors: nothing may unwind through the C boundary
   try {
-    return scene_upload(ctx, scene, out);
+    return flatten_scene_checked(scene, out);
   } catch (const std::bad_alloc&) {
     return fail(RTK_ERR_NOMEM, "rtk_scene_upload: out of host memory");
   } catch (...) {
@@ -365,7 +341,7 @@ int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle*
   }
 }
 
-static int scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle** out) {
+static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   if ((scene->n_objects && !scene->objects) || (scene->n_lights && !scene->lights))
     return fail(RTK_ERR_INVALID, "rtk_scene_upload: null object or light array");
   if (scene->max_depth > RTK_MAX_DEPTH_LIMIT) return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: max_depth above RTK_MAX_DEPTH_LIMIT");
@@ -604,68 +580,43 @@ static int scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_hand
         }
   }
 
-  rtk_scene_handle* h = new (std::nothrow) rtk_scene_handle();
-  if (!h) return fail(RTK_ERR_NOMEM, "rtk_scene_upload: out of host memory");
   // One device allocation and one copy for all record arrays (each 256-byte aligned inside it);
   // the per-camera records, which only kernels write, follow at its end.
-  struct Piece {
-    void** dst;
+  struct Source {
     const void* src;
     size_t bytes, offset;
   };
-  std::vector<Piece> pieces;
+  std::vector<Source> sources;
   size_t total = 0;
-  auto place = [&](void** dst, const void* src, size_t bytes) {
-    *dst = nullptr;
+  auto place = [&](void* rtk_scene_handle::*dst, const void* src, size_t bytes) {
     if (bytes == 0) return;
-    pieces.push_back({dst, src, bytes, total});
+    flat.pieces.push_back({dst, bytes, total});
+    if (src) sources.push_back({src, bytes, total});
     total += (bytes + 255u) & ~(size_t)255u;
   };
-  place(&h->d_objects, objects.data(), objects.size() * sizeof(DevObject));
-  place(&h->d_lights, lights.data(), lights.size() * sizeof(DevLight));
-  place(&h->d_filter, filter.data(), filter.size() * sizeof(float4));
-  place(&h->d_exact, sph_exact.data(), sph_exact.size() * sizeof(double4));
-  place(&h->d_sph_object, sph_object.data(), sph_object.size() * sizeof(uint32_t));
-  place(&h->d_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
-  place(&h->d_pattern_inv, pattern_inv.data(), pattern_inv.size() * sizeof(double));
-  place(&h->d_light_filter, light_filter.data(), light_filter.size() * sizeof(float4));
-  place(&h->d_light_kind, light_kind.data(), light_kind.size() * sizeof(uint32_t));
-  place(&h->d_k_table, k_table.data(), k_table.size() * sizeof(float));
-  place(&h->d_sph_tab, sph_tab.data(), sph_tab.size() * sizeof(float4));
-  place(&h->d_sph_ball, sph_ball.data(), sph_ball.size() * sizeof(float4));
-  place(&h->d_cluster_ball, cluster_ball.data(), cluster_ball.size() * sizeof(float4));
+  place(&rtk_scene_handle::d_objects, objects.data(), objects.size() * sizeof(DevObject));
+  place(&rtk_scene_handle::d_lights, lights.data(), lights.size() * sizeof(DevLight));
+  place(&rtk_scene_handle::d_filter, filter.data(), filter.size() * sizeof(float4));
+  place(&rtk_scene_handle::d_exact, sph_exact.data(), sph_exact.size() * sizeof(double4));
+  place(&rtk_scene_handle::d_sph_object, sph_object.data(), sph_object.size() * sizeof(uint32_t));
+  place(&rtk_scene_handle::d_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
+  place(&rtk_scene_handle::d_pattern_inv, pattern_inv.data(), pattern_inv.size() * sizeof(double));
+  place(&rtk_scene_handle::d_light_filter, light_filter.data(), light_filter.size() * sizeof(float4));
+  place(&rtk_scene_handle::d_light_kind, light_kind.data(), light_kind.size() * sizeof(uint32_t));
+  place(&rtk_scene_handle::d_k_table, k_table.data(), k_table.size() * sizeof(float));
+  place(&rtk_scene_handle::d_sph_tab, sph_tab.data(), sph_tab.size() * sizeof(float4));
+  place(&rtk_scene_handle::d_sph_ball, sph_ball.data(), sph_ball.size() * sizeof(float4));
+  place(&rtk_scene_handle::d_cluster_ball, cluster_ball.data(), cluster_ball.size() * sizeof(float4));
   const size_t copied = total;
-  place((void**)&h->d_prim, nullptr, n_pad * sizeof(float4));
-  place((void**)&h->d_prim_ball, nullptr, n_pad * sizeof(float4));
-  place((void**)&h->d_prim_cluster, nullptr, n_pad ? n_clusters_pad * sizeof(float4) : 0);
-  hipError_t e = hipSetDevice(ctx->device);
-  if (e == hipSuccess && total) {
-    std::vector<unsigned char> staged(copied, 0);
-    for (const Piece& p : pieces)
-      if (p.src) std::memcpy(staged.data() + p.offset, p.src, p.bytes);
-    e = hipMalloc(&h->d_block, total);
-    if (e == hipSuccess && copied) e = hipMemcpy(h->d_block, staged.data(), copied, hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-      for (const Piece& p : pieces) *p.dst = (unsigned char*)h->d_block + p.offset;
-  }
-  if (e != hipSuccess) {
-    rtk_scene_release(ctx, h);
-    return fail_hip(e, "rtk_scene_upload");
-  }
-  DevScene& d = h->dev;
-  d.objects = (const DevObject*)h->d_objects;
-  d.lights = (const DevLight*)h->d_lights;
-  d.sph_filter = (const float4*)h->d_filter;
-  d.sph_exact = (const double4*)h->d_exact;
-  d.sph_object = (const uint32_t*)h->d_sph_object;
-  d.plane_object = (const uint32_t*)h->d_plane_object;
-  d.pattern_inv = (const double*)h->d_pattern_inv;
-  d.light_filter = (const float4*)h->d_light_filter;
-  d.light_kind = (const uint32_t*)h->d_light_kind;
-  d.k_table = (const float4*)h->d_k_table;
-  d.sph_tab = (const float4*)h->d_sph_tab;
-  d.sph_ball = (const float4*)h->d_sph_ball;
-  d.cluster_ball = (const float4*)h->d_cluster_ball;
+  place(&rtk_scene_handle::d_prim, nullptr, n_pad * sizeof(float4));
+  place(&rtk_scene_handle::d_prim_ball, nullptr, n_pad * sizeof(float4));
+  place(&rtk_scene_handle::d_prim_cluster, nullptr, n_pad ? n_clusters_pad * sizeof(float4) : 0);
+  flat.total = total;
+  flat.staged.assign(copied, 0);
+  for (const Source& p : sources) std::memcpy(flat.staged.data() + p.offset, p.src, p.bytes);
+
+  DevScene& d = flat.dev;
+  d = DevScene{};
   d.n_clusters_padded = n_clusters_pad;
   d.lights_uniform = lights_uniform ? 1u : 0u;
   d.lights_bundled = lights_bundled ? 1u : 0u;
@@ -684,6 +635,40 @@ static int scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_hand
   d.r2_max = r2_max;
   d.r_max = r_max;
   d.c_max = c_max;
+  return RTK_OK;
+}
+
+int rtk::place_scene(rtk_context* ctx, const rtk::FlatScene& flat, rtk_scene_handle** out) {
+  *out = nullptr;
+  rtk_scene_handle* h = new (std::nothrow) rtk_scene_handle();
+  if (!h) return fail(RTK_ERR_NOMEM, "rtk_scene_upload: out of host memory");
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess && flat.total) {
+    e = hipMalloc(&h->d_block, flat.total);
+    if (e == hipSuccess && !flat.staged.empty())
+      e = hipMemcpy(h->d_block, flat.staged.data(), flat.staged.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+      for (const rtk::FlatScene::Piece& p : flat.pieces) h->*(p.dst) = (unsigned char*)h->d_block + p.offset;
+  }
+  if (e != hipSuccess) {
+    rtk_scene_release(ctx, h);
+    return fail_hip(e, "rtk_scene_upload");
+  }
+  rtk::DevScene& d = h->dev;
+  d = flat.dev;
+  d.objects = (const rtk::DevObject*)h->d_objects;
+  d.lights = (const rtk::DevLight*)h->d_lights;
+  d.sph_filter = (const float4*)h->d_filter;
+  d.sph_exact = (const double4*)h->d_exact;
+  d.sph_object = (const uint32_t*)h->d_sph_object;
+  d.plane_object = (const uint32_t*)h->d_plane_object;
+  d.pattern_inv = (const double*)h->d_pattern_inv;
+  d.light_filter = (const float4*)h->d_light_filter;
+  d.light_kind = (const uint32_t*)h->d_light_kind;
+  d.k_table = (const float4*)h->d_k_table;
+  d.sph_tab = (const float4*)h->d_sph_tab;
+  d.sph_ball = (const float4*)h->d_sph_ball;
+  d.cluster_ball = (const float4*)h->d_cluster_ball;
   *out = h;
   return RTK_OK;
 }
@@ -706,6 +691,70 @@ static int make_dev_camera(const rtk_camera* camera, rtk::DevCamera& c) {
   return RTK_OK;
 }
 
+// ---------------------------------------------------------------- partitions
+static uint32_t tiles_across(uint32_t width) { return (width + RTK_TILE_W - 1) / RTK_TILE_W; }
+static uint32_t tiles_down(uint32_t height) { return (height + RTK_TILE_H - 1) / RTK_TILE_H; }
+
+int rtk::partition_from_tiling(const rtk_camera* camera, const rtk_tiling* tiling, rtk::Partition& p, const char* who) {
+  rtk_tiling tl = {0u, 1u};
+  if (tiling) tl = *tiling;
+  if (tl.world == 0 || tl.rank >= tl.world) return fail(RTK_ERR_INVALID, std::string(who) + ": bad tiling (rank >= world)");
+  p = rtk::Partition{};
+  p.layout = tl.world > 1 ? 1u : 0u;
+  p.step = tl.world;
+  p.offset = tl.rank;
+  p.n_local_tiles = rtk_tiles_for_rank(camera->width, camera->height, tl.rank, tl.world);
+  return RTK_OK;
+}
+
+// Tile rows of [first, first + n) that the bands dealt to `rank` hold.
+static uint64_t band_rows_of_rank(uint32_t rows, uint32_t m, uint32_t rank, uint32_t world) {
+  const uint32_t bands = (rows + m - 1) / m;
+  uint64_t mine = 0;
+  for (uint32_t b = rank; b < bands; b += world) mine += std::min(m, rows - b * m);
+  return mine;
+}
+static bool banding_rows(uint32_t height, const rtk_banding* bd, uint32_t& rows) {
+  if (!bd || bd->world == 0 || bd->rank >= bd->world || bd->band_tile_rows == 0) return false;
+  const uint32_t ty = tiles_down(height);
+  if (bd->first_tile_row > ty) return false;
+  rows = ty - bd->first_tile_row;
+  if (bd->n_tile_rows) {
+    if (bd->n_tile_rows > rows) return false;
+    rows = bd->n_tile_rows;
+  }
+  return true;
+}
+
+int rtk::partition_from_banding(const rtk_camera* camera, const rtk_banding* banding, rtk::Partition& p, const char* who) {
+  uint32_t rows = 0;
+  if (!banding_rows(camera->height, banding, rows))
+    return fail(RTK_ERR_INVALID, std::string(who) + ": bad banding (rank >= world, band_tile_rows == 0, or rows outside the frame)");
+  p = rtk::Partition{};
+  p.layout = banding->compact ? 2u : 0u;
+  p.band_rows = banding->band_tile_rows;
+  p.band_world = banding->world;
+  p.band_rank = banding->rank;
+  p.row0 = banding->first_tile_row;
+  p.n_local_tiles = band_rows_of_rank(rows, banding->band_tile_rows, banding->rank, banding->world) * tiles_across(camera->width);
+  return RTK_OK;
+}
+
+extern "C" {
+
+uint64_t rtk_band_tile_rows(uint32_t height, const rtk_banding* banding) {
+  uint32_t rows = 0;
+  if (height == 0 || !banding_rows(height, banding, rows)) return 0;
+  return band_rows_of_rank(rows, banding->band_tile_rows, banding->rank, banding->world);
+}
+
+uint64_t rtk_band_pixel_rows(uint32_t height, const rtk_banding* banding) {
+  return rtk_band_tile_rows(height, banding) * (uint64_t)RTK_TILE_H;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- one frame on one device
 // What follows the render kernels inside the timed region of a sampled call: the sample frame
 // d_rgb_f32 of the (supersampled) camera is averaged into the caller's frame.
 struct ResolveStep {
@@ -714,71 +763,151 @@ struct ResolveStep {
   float* d_rgb = nullptr;
   uint8_t* d_rgba8 = nullptr;
   bool tiles = false;  // the sample frame is a rank's compact tile buffer
+  uint64_t n_tiles = 0;
 };
 
-static int render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, const rtk_tiling* tiling,
-                         float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream, const ResolveStep& resolve) {
-  if (!ctx || !scene || !camera) return fail(RTK_ERR_INVALID, "rtk_render_device: null argument");
-  rtk::DevCamera cam;
-  int rc = make_dev_camera(camera, cam);
+// Device memory a frame's kernels use beyond the scene, the camera and the outputs.
+struct Scratch {
+  float4 *prim = nullptr, *prim_ball = nullptr, *prim_cluster = nullptr;  // per-camera records
+  rtk::DevCounters* counters = nullptr;
+  rtk::OpaqueBuffers opaque{};  // hit records of the three-kernel path (null when not needed)
+};
+
+// A frame in the making: frame_begin, one or more frame_launch, frame_end.
+struct Frame {
+  rtk_context* ctx = nullptr;
+  rtk_scene_handle* scene = nullptr;
+  const rtk_camera* camera = nullptr;
+  rtk::DevCamera cam{};
+  hipStream_t st = nullptr;
+  int slot = 0;
+  bool opaque = false;
+  Scratch scr;
+};
+
+// Records of the three-kernel path for launches of up to `pixels` pixels, in the context's own
+// buffers (grown on demand).
+static int context_records(rtk_context* ctx, size_t pixels, rtk::OpaqueBuffers& out) {
+  if (pixels > ctx->cap_opaque) {
+    if (ctx->opaque.hit_obj) (void)hipFree(ctx->opaque.hit_obj);
+    if (ctx->opaque.hit_t) (void)hipFree(ctx->opaque.hit_t);
+    if (ctx->opaque.shadow) (void)hipFree(ctx->opaque.shadow);
+    ctx->opaque = rtk::OpaqueBuffers{};
+    ctx->cap_opaque = 0;
+    RTK_HIP(hipMalloc((void**)&ctx->opaque.hit_obj, pixels * sizeof(uint32_t)));
+    RTK_HIP(hipMalloc((void**)&ctx->opaque.hit_t, pixels * sizeof(double)));
+    RTK_HIP(hipMalloc((void**)&ctx->opaque.shadow, pixels));
+    ctx->cap_opaque = pixels;
+  }
+  out = ctx->opaque;
+  return RTK_OK;
+}
+
+// Orders this call behind the context's previous one (they share per-camera records, counters
+// and hit records), resets the counters, rebuilds the per-camera records and starts the timing.
+static int frame_begin(Frame& f, rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, void* hip_stream,
+                       const Scratch& scr) {
+  f.ctx = ctx, f.scene = scene, f.camera = camera, f.scr = scr;
+  const int rc = make_dev_camera(camera, f.cam);
   if (rc != RTK_OK) return rc;
-  rtk_tiling tl = {0u, 1u};
-  if (tiling) tl = *tiling;
-  if (tl.world == 0 || tl.rank >= tl.world) return fail(RTK_ERR_INVALID, "rtk_render_device: bad tiling (rank >= world)");
+  RTK_HIP(hipSetDevice(ctx->device));
+  f.st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  f.opaque = !scene->dev.any_secondary;
+  if (ctx->n_timed && ctx->last_stream != f.st)
+    RTK_HIP(hipStreamWaitEvent(f.st, ctx->ev_stop[(ctx->n_timed - 1) % RTK_TIMING_HISTORY], 0));
+  RTK_HIP(hipMemsetAsync(f.scr.counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, f.st));
+  RTK_HIP(rtk::launch_prep_primary(f.st, scene->dev, f.cam, f.scr.prim, f.scr.prim_ball, f.scr.prim_cluster));
+  f.slot = (int)(ctx->n_timed % RTK_TIMING_HISTORY);
+  RTK_HIP(hipEventRecord(ctx->ev_start[f.slot], f.st));  // the per-camera record kernel (microseconds) stays outside
+  ctx->ev_split[f.slot] = false;
+  return RTK_OK;
+}
+
+// Renders the tiles of one partition.  `split`: record the end-of-ray-kernels event (a frame
+// made of one launch only).
+static int frame_launch(Frame& f, const rtk::Partition& p, float* d_rgb_f32, uint8_t* d_rgba8, bool split) {
+  // per-launch pixel indices (local tile * 256 + slot) are 32-bit
+  if (p.n_local_tiles > 0x00ffffffull)
+    return fail(RTK_ERR_UNSUPPORTED, "rtk_render_device: more than 16,777,215 tiles (4.29e9 pixels) per launch");
   rtk::RenderTarget t{};
   t.rgb = d_rgb_f32;
   t.rgba8 = d_rgba8;
-  t.tiles_x = (camera->width + RTK_TILE_W - 1) / RTK_TILE_W;
-  t.tiles_y = (camera->height + RTK_TILE_H - 1) / RTK_TILE_H;
-  t.rank = tl.rank;
-  t.world = tl.world;
-  const uint64_t n_local = rtk_tiles_for_rank(camera->width, camera->height, tl.rank, tl.world);
-  // per-launch pixel indices (local tile * 256 + slot) are 32-bit
-  if (n_local > 0x00ffffffull) return fail(RTK_ERR_UNSUPPORTED, "rtk_render_device: more than 16,777,215 tiles (4.29e9 pixels) per launch");
-  t.n_local_tiles = (uint32_t)n_local;
-  t.compact = tl.world > 1 ? 1u : 0u;
-
-  RTK_HIP(hipSetDevice(ctx->device));
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-  const bool opaque = !scene->dev.any_secondary;
-  if (opaque) {
-    // intermediate hit / shadow records: one entry per pixel of this launch
-    const size_t need = (size_t)t.n_local_tiles * 256u;
-    if (need > ctx->cap_opaque) {
-      if (ctx->opaque.hit_obj) (void)hipFree(ctx->opaque.hit_obj);
-      if (ctx->opaque.hit_t) (void)hipFree(ctx->opaque.hit_t);
-      if (ctx->opaque.shadow) (void)hipFree(ctx->opaque.shadow);
-      ctx->opaque = rtk::OpaqueBuffers{};
-      ctx->cap_opaque = 0;
-      RTK_HIP(hipMalloc((void**)&ctx->opaque.hit_obj, need * sizeof(uint32_t)));
-      RTK_HIP(hipMalloc((void**)&ctx->opaque.hit_t, need * sizeof(double)));
-      RTK_HIP(hipMalloc((void**)&ctx->opaque.shadow, need));
-      ctx->cap_opaque = need;
-    }
+  t.tiles_x = tiles_across(f.camera->width);
+  t.tiles_y = tiles_down(f.camera->height);
+  t.n_local_tiles = (uint32_t)p.n_local_tiles;
+  t.layout = p.layout;
+  t.step = p.step, t.offset = p.offset;
+  t.band_rows = p.band_rows, t.band_world = p.band_world, t.band_rank = p.band_rank, t.row0 = p.row0;
+  rtk_context* ctx = f.ctx;
+  if (f.opaque) {
+    if (split) ctx->ev_split[f.slot] = true;
+    RTK_HIP(rtk::launch_render_opaque(f.st, f.scene->dev, f.cam, f.scr.prim, f.scr.prim_ball, f.scr.prim_cluster, t,
+                                      f.scr.opaque, f.scr.counters, split ? ctx->ev_rays[f.slot] : nullptr));
+  } else {
+    RTK_HIP(rtk::launch_render(f.st, f.scene->dev, f.cam, f.scr.prim, f.scr.prim_cluster, t, f.scr.counters));
   }
-  RTK_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, st));
-  RTK_HIP(rtk::launch_prep_primary(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball, scene->d_prim_cluster));
-  const int slot = (int)(ctx->n_timed % RTK_TIMING_HISTORY);
-  RTK_HIP(hipEventRecord(ctx->ev_start[slot], st));  // the per-camera record kernel (microseconds) stays outside
-  ctx->ev_split[slot] = opaque;
-  if (opaque)
-    RTK_HIP(rtk::launch_render_opaque(st, scene->dev, cam, scene->d_prim, scene->d_prim_ball, scene->d_prim_cluster, t,
-                                      ctx->opaque, ctx->d_counters, ctx->ev_rays[slot]));
-  else
-    RTK_HIP(rtk::launch_render(st, scene->dev, cam, scene->d_prim, scene->d_prim_cluster, t, ctx->d_counters));
+  return RTK_OK;
+}
+
+static int frame_end(Frame& f, const ResolveStep& resolve, const float* d_samples) {
+  rtk_context* ctx = f.ctx;
   if (resolve.s > 1 && resolve.tiles)
-    RTK_HIP(rtk::launch_resolve_tiles(st, t.n_local_tiles, resolve.s, d_rgb_f32, resolve.d_rgb, resolve.d_rgba8));
+    RTK_HIP(rtk::launch_resolve_tiles(f.st, resolve.n_tiles, resolve.s, d_samples, resolve.d_rgb, resolve.d_rgba8));
   else if (resolve.s > 1)
-    RTK_HIP(rtk::launch_resolve(st, resolve.width, resolve.height, resolve.s, d_rgb_f32, resolve.d_rgb, resolve.d_rgba8));
-  RTK_HIP(hipEventRecord(ctx->ev_stop[slot], st));
-  ctx->last_stream = st;
+    RTK_HIP(rtk::launch_resolve(f.st, resolve.width, resolve.height, resolve.s, d_samples, resolve.d_rgb, resolve.d_rgba8));
+  RTK_HIP(hipEventRecord(ctx->ev_stop[f.slot], f.st));
+  ctx->last_stream = f.st;
+  ctx->last_counters = f.scr.counters;
   ++ctx->n_timed;
   return RTK_OK;
 }
 
+// Scratch in memory of the scene handle (per-camera records) and the context (counters, hit records).
+static int context_scratch(rtk_context* ctx, rtk_scene_handle* scene, size_t launch_pixels, Scratch& scr) {
+  scr.prim = (float4*)scene->d_prim;
+  scr.prim_ball = (float4*)scene->d_prim_ball;
+  scr.prim_cluster = (float4*)scene->d_prim_cluster;
+  scr.counters = ctx->d_counters;
+  scr.opaque = rtk::OpaqueBuffers{};
+  if (!scene->dev.any_secondary && rtk::opaque_needs_records(scene->dev)) {
+    RTK_HIP(hipSetDevice(ctx->device));
+    return context_records(ctx, launch_pixels, scr.opaque);
+  }
+  return RTK_OK;
+}
+
+static int render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, const rtk::Partition& p,
+                         float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream, const ResolveStep& resolve) {
+  if (camera->width == 0 || camera->height == 0) return fail(RTK_ERR_INVALID, "camera has zero size");
+  Scratch scr;
+  int rc = context_scratch(ctx, scene, (size_t)p.n_local_tiles * 256u, scr);
+  if (rc != RTK_OK) return rc;
+  Frame f;
+  if ((rc = frame_begin(f, ctx, scene, camera, hip_stream, scr)) != RTK_OK) return rc;
+  if ((rc = frame_launch(f, p, d_rgb_f32, d_rgba8, true)) != RTK_OK) return rc;
+  ResolveStep step = resolve;
+  step.n_tiles = p.n_local_tiles;
+  return frame_end(f, step, d_rgb_f32);
+}
+
+extern "C" {
+
 int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, const rtk_tiling* tiling,
                       float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream) {
-  return render_device(ctx, scene, camera, tiling, d_rgb_f32, d_rgba8, hip_stream, ResolveStep{});
+  if (!ctx || !scene || !camera) return fail(RTK_ERR_INVALID, "rtk_render_device: null argument");
+  rtk::Partition p;
+  const int rc = rtk::partition_from_tiling(camera, tiling, p, "rtk_render_device");
+  if (rc != RTK_OK) return rc;
+  return render_device(ctx, scene, camera, p, d_rgb_f32, d_rgba8, hip_stream, ResolveStep{});
+}
+
+int rtk_render_device_bands(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, const rtk_banding* banding,
+                            float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream) {
+  if (!ctx || !scene || !camera || !banding) return fail(RTK_ERR_INVALID, "rtk_render_device_bands: null argument");
+  rtk::Partition p;
+  const int rc = rtk::partition_from_banding(camera, banding, p, "rtk_render_device_bands");
+  if (rc != RTK_OK) return rc;
+  return render_device(ctx, scene, camera, p, d_rgb_f32, d_rgba8, hip_stream, ResolveStep{});
 }
 
 int rtk_camera_supersample(const rtk_camera* camera, uint32_t s, rtk_camera* out) {
@@ -809,10 +938,11 @@ int rtk_render_device_sampled(rtk_context* ctx, rtk_scene_handle* scene, const r
   rtk_camera fine;
   int rc = rtk_camera_supersample(camera, s, &fine);
   if (rc != RTK_OK) return rc;
-  if (s == 1) return render_device(ctx, scene, camera, tiling, d_rgb_f32, d_rgba8, hip_stream, ResolveStep{});
   rtk_tiling tl = {0u, 1u};
   if (tiling) tl = *tiling;
-  if (tl.world == 0 || tl.rank >= tl.world) return fail(RTK_ERR_INVALID, "rtk_render_device_sampled: bad tiling (rank >= world)");
+  rtk::Partition p;
+  if ((rc = rtk::partition_from_tiling(&fine, &tl, p, "rtk_render_device_sampled")) != RTK_OK) return rc;
+  if (s == 1) return render_device(ctx, scene, camera, p, d_rgb_f32, d_rgba8, hip_stream, ResolveStep{});
   if (tl.world > 1 && 8u % s != 0)
     return fail(RTK_ERR_UNSUPPORTED, "rtk_render_device_sampled: with world > 1 samples_per_axis must be 1, 2, 4 or 8");
   RTK_HIP(hipSetDevice(ctx->device));
@@ -831,7 +961,7 @@ int rtk_render_device_sampled(rtk_context* ctx, rtk_scene_handle* scene, const r
   step.s = s, step.width = camera->width, step.height = camera->height;
   step.d_rgb = d_rgb_f32, step.d_rgba8 = d_rgba8;
   step.tiles = tl.world > 1;
-  return render_device(ctx, scene, &fine, &tl, ctx->d_samples, nullptr, hip_stream, step);
+  return render_device(ctx, scene, &fine, p, ctx->d_samples, nullptr, hip_stream, step);
 }
 
 int rtk_resolve(rtk_context* ctx, uint32_t width, uint32_t height, uint32_t s, const float* d_samples_rgb_f32,
@@ -866,7 +996,7 @@ int rtk_get_stats(rtk_context* ctx, rtk_stats* stats) {
   const int rc = slot_times(ctx, slot, &stats->kernel_ms, &stats->rays_ms);
   if (rc != RTK_OK) return rc;
   rtk::DevCounters shards[rtk::kCounterShards];
-  RTK_HIP(hipMemcpyAsync(shards, ctx->d_counters, sizeof shards, hipMemcpyDeviceToHost, ctx->last_stream));
+  RTK_HIP(hipMemcpyAsync(shards, ctx->last_counters, sizeof shards, hipMemcpyDeviceToHost, ctx->last_stream));
   RTK_HIP(hipStreamSynchronize(ctx->last_stream));
   for (const rtk::DevCounters& c : shards) {
     stats->rays_primary += c.rays_primary;
@@ -899,11 +1029,52 @@ int rtk_render(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camer
   return rtk_render_sampled(ctx, scene, camera, 1, rgb_f32_out, rgba8_out, stats);
 }
 
+// The frame of `camera` into host buffers, one sample per pixel: the frame is cut into blocks of
+// whole tile rows, rendered bottom-up on the context's stream; each block's rows start for the
+// host on the copy stream as soon as its kernel has finished, while the next block renders.
+static int render_to_host(rtk_context* ctx, rtk_scene_handle* h, const rtk_camera* camera, float* rgb_f32_out,
+                          uint8_t* rgba8_out) {
+  const uint32_t width = camera->width, height = camera->height;
+  const uint32_t rows = tiles_down(height);
+  const uint32_t n_blocks = (uint64_t)width * height >= (1u << 20) ? std::min<uint32_t>(rtk_context::kHostBlocks, rows) : 1u;
+  const uint32_t per_block = (rows + n_blocks - 1) / n_blocks;
+  Scratch scr;
+  int rc = context_scratch(ctx, h, (size_t)per_block * tiles_across(width) * 256u, scr);
+  if (rc != RTK_OK) return rc;
+  Frame f;
+  if ((rc = frame_begin(f, ctx, h, camera, nullptr, scr)) != RTK_OK) return rc;
+  float* d_rgb = rgb_f32_out ? ctx->d_rgb : nullptr;
+  uint8_t* d_rgba8 = rgba8_out ? ctx->d_rgba8 : nullptr;
+  for (uint32_t i = 0; i < n_blocks; ++i) {
+    const uint32_t b = n_blocks - 1u - i;  // bottom block first
+    const uint32_t row_a = b * per_block, row_b = std::min(rows, row_a + per_block);
+    if (row_a >= row_b) continue;
+    rtk_banding bd = {0u, 1u, row_b - row_a, row_a, row_b - row_a, 0u};
+    rtk::Partition p;
+    if ((rc = rtk::partition_from_banding(camera, &bd, p, "rtk_render")) != RTK_OK) return rc;
+    if ((rc = frame_launch(f, p, d_rgb, d_rgba8, n_blocks == 1u)) != RTK_OK) return rc;
+    RTK_HIP(hipEventRecord(ctx->ev_block[i], f.st));
+    RTK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_block[i], 0));
+    const size_t y0 = (size_t)row_a * RTK_TILE_H, y1 = std::min<size_t>(height, (size_t)row_b * RTK_TILE_H);
+    const size_t first = y0 * width, count = (y1 - y0) * width;
+    if (rgb_f32_out)
+      RTK_HIP(hipMemcpyAsync(rgb_f32_out + first * 3, d_rgb + first * 3, count * 3 * sizeof(float), hipMemcpyDeviceToHost,
+                             ctx->copy_stream));
+    if (rgba8_out)
+      RTK_HIP(hipMemcpyAsync(rgba8_out + first * 4, d_rgba8 + first * 4, count * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
+  }
+  if ((rc = frame_end(f, ResolveStep{}, nullptr)) != RTK_OK) return rc;
+  RTK_HIP(hipStreamSynchronize(ctx->copy_stream));
+  RTK_HIP(hipStreamSynchronize(ctx->stream));
+  return RTK_OK;
+}
+
 int rtk_render_sampled(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camera, uint32_t samples_per_axis,
                        float* rgb_f32_out, uint8_t* rgba8_out, rtk_stats* stats) {
   if (!ctx || !scene || !camera) return fail(RTK_ERR_INVALID, "rtk_render: null argument");
   if (samples_per_axis == 0 || samples_per_axis > RTK_MAX_SAMPLES_PER_AXIS)
     return fail(RTK_ERR_INVALID, "rtk_render_sampled: samples_per_axis must be 1.." + std::to_string(RTK_MAX_SAMPLES_PER_AXIS));
+  if (camera->width == 0 || camera->height == 0) return fail(RTK_ERR_INVALID, "camera has zero size");
   rtk_scene_handle* h = nullptr;
   int rc = rtk_scene_upload(ctx, scene, &h);
   if (rc != RTK_OK) return rc;
@@ -922,15 +1093,19 @@ int rtk_render_sampled(rtk_context* ctx, const rtk_scene* scene, const rtk_camer
     }
     ctx->cap_pixels = pixels;
   }
-  rc = rtk_render_device_sampled(ctx, h, camera, samples_per_axis, nullptr, rgb_f32_out ? ctx->d_rgb : nullptr,
-                                 rgba8_out ? ctx->d_rgba8 : nullptr, nullptr);
-  hipError_t e = hipSuccess;
-  if (rc == RTK_OK && rgb_f32_out)
-    e = hipMemcpyAsync(rgb_f32_out, ctx->d_rgb, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-  if (rc == RTK_OK && e == hipSuccess && rgba8_out)
-    e = hipMemcpyAsync(rgba8_out, ctx->d_rgba8, pixels * 4, hipMemcpyDeviceToHost, ctx->stream);
-  if (rc == RTK_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (rc == RTK_OK && e != hipSuccess) rc = fail_hip(e, "rtk_render: copy back");
+  if (samples_per_axis == 1) {
+    rc = render_to_host(ctx, h, camera, rgb_f32_out, rgba8_out);
+  } else {
+    rc = rtk_render_device_sampled(ctx, h, camera, samples_per_axis, nullptr, rgb_f32_out ? ctx->d_rgb : nullptr,
+                                   rgba8_out ? ctx->d_rgba8 : nullptr, nullptr);
+    hipError_t e = hipSuccess;
+    if (rc == RTK_OK && rgb_f32_out)
+      e = hipMemcpyAsync(rgb_f32_out, ctx->d_rgb, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (rc == RTK_OK && e == hipSuccess && rgba8_out)
+      e = hipMemcpyAsync(rgba8_out, ctx->d_rgba8, pixels * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (rc == RTK_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (rc == RTK_OK && e != hipSuccess) rc = fail_hip(e, "rtk_render: copy back");
+  }
   if (rc == RTK_OK && stats) rc = rtk_get_stats(ctx, stats);
   rtk_scene_release(ctx, h);
   return rc;
@@ -950,6 +1125,8 @@ int rtk_trace_rays(rtk_context* ctx, rtk_scene_handle* scene, const double* orig
   if (e == hipSuccess) e = hipMalloc((void**)&d_d, n * 4 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&d_c, n * 3 * sizeof(double));
   hipStream_t st = ctx->stream;
+  if (e == hipSuccess && ctx->n_timed && ctx->last_stream != st)  // behind the context's previous call (shared counters)
+    e = hipStreamWaitEvent(st, ctx->ev_stop[(ctx->n_timed - 1) % RTK_TIMING_HISTORY], 0);
   if (e == hipSuccess) e = hipMemcpyAsync(d_o, origins, n * 4 * sizeof(double), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_d, directions, n * 4 * sizeof(double), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, st);
@@ -965,6 +1142,7 @@ int rtk_trace_rays(rtk_context* ctx, rtk_scene_handle* scene, const double* orig
   if (d_c) (void)hipFree(d_c);
   if (e != hipSuccess) return fail_hip(e, "rtk_trace_rays");
   ctx->last_stream = st;
+  ctx->last_counters = ctx->d_counters;
   ++ctx->n_timed;
   return RTK_OK;
 }

@@ -103,10 +103,29 @@ struct RenderTarget {
   float* rgb;        // may be null
   uint8_t* rgba8;    // may be null
   uint32_t tiles_x, tiles_y;
-  uint32_t rank, world;  // this launch renders tiles t with t % world == rank
   uint32_t n_local_tiles;
-  uint32_t compact;  // 1: tile-major compact layout, 0: row-major frame
+  uint32_t layout;  // 0: row-major frame; 1: the rank's tiles one after the other (tile-major); 2: the rank's tile rows one after the other
+  // Local tile k of the launch is entry g = k * step + offset of a row-major walk over tile rows
+  // of tiles_x tiles; row q = g / tiles_x of that walk is row q % band_rows of band q / band_rows,
+  // and that band is the global band (q / band_rows) * band_world + band_rank counted from tile row row0.
+  //   tiles dealt round-robin to `world` ranks: step = world, offset = rank, band_rows = 1, band_world = 1, band_rank = 0
+  //   bands of m tile rows dealt round-robin:   step = 1, offset = 0, band_rows = m, band_world = world, band_rank = rank
+  uint32_t step, offset;
+  uint32_t band_rows, band_world, band_rank, row0;
 };
+
+struct TileRef {
+  uint32_t tx, ty;  // tile coordinates in the frame
+  uint32_t lrow;    // row of the launch's own walk (the local tile row in band mode)
+};
+__device__ __forceinline__ TileRef tile_ref(const RenderTarget& T, uint32_t k) {
+  TileRef r;
+  const uint32_t g = k * T.step + T.offset;
+  r.tx = g % T.tiles_x;
+  r.lrow = g / T.tiles_x;
+  r.ty = T.row0 + ((r.lrow / T.band_rows) * T.band_world + T.band_rank) * T.band_rows + r.lrow % T.band_rows;
+  return r;
+}
 
 }  // namespace rtk
 #endif

@@ -1,0 +1,108 @@
+// rtk_internal.h -- what the host-side translation units of the library share: the opaque
+// handles of include/rtk.h, error reporting, and the single-device render call the multi-device
+// code is built on.  Host code only.
+#ifndef RTK_INTERNAL_H
+#define RTK_INTERNAL_H
+
+#include "../../include/rtk.h"
+#include "rtk_device.h"
+#include "rtk_kernels.h"
+
+#include <string>
+#include <vector>
+
+namespace rtk {
+
+// Sets the thread's error text (rtk_last_error) and returns `code`.
+int fail(int code, const std::string& msg);
+int fail_hip(hipError_t e, const char* what);
+
+}  // namespace rtk
+
+#define RTK_HIP(call)                                      \
+  do {                                                     \
+    hipError_t e_ = (call);                                \
+    if (e_ != hipSuccess) return rtk::fail_hip(e_, #call); \
+  } while (0)
+
+// A scene resident in HBM: one device allocation, the pointers into it, and the argument block
+// the kernels take.
+struct rtk_scene_handle {
+  rtk::DevScene dev{};
+  void* d_block = nullptr;  // the one device allocation every pointer below points into
+  void* d_objects = nullptr;
+  void* d_lights = nullptr;
+  void* d_filter = nullptr;
+  void* d_exact = nullptr;
+  void* d_sph_object = nullptr;
+  void* d_plane_object = nullptr;
+  void* d_light_kind = nullptr;
+  void* d_pattern_inv = nullptr;
+  void* d_prim = nullptr;          // camera-ray filter records (rebuilt per camera)
+  void* d_prim_ball = nullptr;     // camera-ray records of the wavefront-level cone test (rebuilt per camera)
+  void* d_sph_ball = nullptr;
+  void* d_cluster_ball = nullptr;
+  void* d_prim_cluster = nullptr;  // camera-ray records of the cluster balls (rebuilt per camera)
+  void* d_light_filter = nullptr;
+  void* d_k_table = nullptr;
+  void* d_sph_tab = nullptr;
+};
+
+struct rtk_context {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // device-to-host copies of rtk_render, overlapping its kernels
+  // One (start, end of the ray kernels, stop) event triple per recent call, used round-robin, so
+  // that a caller can render many frames back to back and read their kernel times afterwards.
+  hipEvent_t ev_start[RTK_TIMING_HISTORY] = {}, ev_rays[RTK_TIMING_HISTORY] = {}, ev_stop[RTK_TIMING_HISTORY] = {};
+  bool ev_split[RTK_TIMING_HISTORY] = {};  // ev_rays was recorded by the call that used the slot
+  uint64_t n_timed = 0;                    // calls that recorded a triple; the newest sits in slot (n_timed - 1) % N
+  rtk::DevCounters* d_counters = nullptr;
+  rtk::DevCounters* last_counters = nullptr;  // where the last call counted its rays
+  hipStream_t last_stream = nullptr;
+  // staging for rtk_render (host-buffer variant)
+  float* d_rgb = nullptr;
+  uint8_t* d_rgba8 = nullptr;
+  size_t cap_pixels = 0;
+  static constexpr int kHostBlocks = 8;  // blocks a frame is cut into by rtk_render
+  hipEvent_t ev_block[kHostBlocks] = {};
+  // intermediate records of the three-kernel path (grown on demand, kept for the next frame)
+  rtk::OpaqueBuffers opaque{};
+  size_t cap_opaque = 0;
+  // sample frame of rtk_render_device_sampled (grown on demand)
+  float* d_samples = nullptr;
+  size_t cap_samples = 0;  // in samples
+};
+
+namespace rtk {
+
+// A scene flattened for the device, not yet on one: the bytes of the record arrays laid out as
+// they will lie in the device allocation, and the kernels' argument block with its pointers unset.
+struct FlatScene {
+  struct Piece {
+    void* rtk_scene_handle::*dst;
+    size_t bytes, offset;
+  };
+  std::vector<Piece> pieces;
+  std::vector<unsigned char> staged;  // the first `staged.size()` bytes of the allocation
+  size_t total = 0;                   // allocation size (the per-camera records follow the staged part)
+  DevScene dev{};
+};
+// Validation and flattening (host work only); RTK_OK or an rtk_status with the error text set.
+int flatten_scene(const rtk_scene* scene, FlatScene& out);
+// Allocates on ctx's device, copies, and fills a new handle.
+int place_scene(rtk_context* ctx, const FlatScene& flat, rtk_scene_handle** out);
+
+// Which tiles of the frame a launch renders and where they go: the host-side form of RenderTarget.
+struct Partition {
+  uint32_t layout = 0;  // 0 frame, 1 tile-major compact, 2 the rank's tile rows one after the other
+  uint32_t step = 1, offset = 0;
+  uint32_t band_rows = 1, band_world = 1, band_rank = 0, row0 = 0;
+  uint64_t n_local_tiles = 0;
+};
+int partition_from_tiling(const rtk_camera* camera, const rtk_tiling* tiling, Partition& p, const char* who);
+int partition_from_banding(const rtk_camera* camera, const rtk_banding* banding, Partition& p, const char* who);
+
+}  // namespace rtk
+
+#endif

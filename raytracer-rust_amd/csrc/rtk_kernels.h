@@ -25,6 +25,9 @@ hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCame
                                 const float4* prim_ball, const float4* prim_cluster, const RenderTarget& T,
                                 const OpaqueBuffers& B, DevCounters* counters, hipEvent_t after_rays);
 
+// True when launch_render_opaque runs its three-kernel path for S and reads / writes the per-pixel records B.
+bool opaque_needs_records(const DevScene& S);
+
 // Traces n caller-supplied rays (device pointers, n x 4 doubles in, n x 3 doubles out).
 hipError_t launch_trace_rays(hipStream_t st, const DevScene& S, const double* origins, const double* directions, uint64_t n,
                              double* colors, DevCounters* counters);

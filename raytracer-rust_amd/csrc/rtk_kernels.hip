@@ -257,15 +257,15 @@ template <bool SECONDARY, int LB, bool WIDE, bool BRUTE, bool TRACK>
 __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                         const float4* __restrict__ prim_cluster, RenderTarget T,
                                                         DevCounters* counters) {
-  __shared__ float4 s_buf[256];  // store transpose only: [256][3] floats + [256] packed pixels
+  __shared__ float s_rgb[768];  // store transpose only
+  __shared__ uint32_t s_px[256];
 
   // expensive tiles (ground, bottom of the frame) first, cheap sky tiles last
   const uint32_t k = T.n_local_tiles - 1u - blockIdx.x;
-  const uint32_t tile = k * T.world + T.rank;
-  const uint32_t tx = tile % T.tiles_x, ty = tile / T.tiles_x;
+  const TileRef tr = tile_ref(T, k);
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t lx = (wave << 3) | (lane & 7u), ly = lane >> 3;
-  const uint32_t x = tx * 32u + lx, y = ty * 8u + ly;
+  const uint32_t x = tr.tx * 32u + lx, y = tr.ty * 8u + ly;
   const bool valid = x < C.width && y < C.height;
 
   const V3 origin = ld3(C.origin);
@@ -274,41 +274,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera
   unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
   V3 color = trace_ray<SECONDARY, true, LB, WIDE, BRUTE, TRACK>(S, prim, prim_cluster, valid, origin, dir, c_primary, c_shadow, c_secondary, c_exact);
 
-  // ---- framebuffer store, transposed through LDS so that every wavefront writes whole
-  // 128-byte (RGBA8) / 384-byte (FP32 RGB) tile rows
-  __syncthreads();
-  float* s_rgb = reinterpret_cast<float*>(s_buf);              // [256][3]
-  uint32_t* s_px = reinterpret_cast<uint32_t*>(s_buf) + 768;  // [256]
-  const uint32_t slot = ly * 32u + lx;
-  s_rgb[slot * 3 + 0] = (float)color.x;
-  s_rgb[slot * 3 + 1] = (float)color.y;
-  s_rgb[slot * 3 + 2] = (float)color.z;
-  s_px[slot] = cast_u8(color.x) | (cast_u8(color.y) << 8) | (cast_u8(color.z) << 16) | 0xff000000u;
-  __syncthreads();
-  {
-    const uint32_t rx = threadIdx.x & 31u, ry = threadIdx.x >> 5;
-    const uint32_t gx = tx * 32u + rx, gy = ty * 8u + ry;
-    if (T.rgba8) {
-      uint32_t* out = reinterpret_cast<uint32_t*>(T.rgba8);
-      if (T.compact)
-        out[(size_t)k * 256u + threadIdx.x] = s_px[threadIdx.x];
-      else if (gx < C.width && gy < C.height)
-        out[(size_t)gx + (size_t)gy * C.width] = s_px[threadIdx.x];
-    }
-    if (T.rgb) {
-#pragma unroll
-      for (uint32_t pass = 0; pass < 3; ++pass) {
-        const uint32_t e = threadIdx.x + pass * 256u;  // element of the tile's [8][96] float image
-        const uint32_t row = e / 96u, col = e % 96u;
-        if (T.compact) {
-          T.rgb[(size_t)k * 768u + e] = s_rgb[e];
-        } else {
-          const uint32_t px = tx * 32u + col / 3u, py = ty * 8u + row;
-          if (px < C.width && py < C.height) T.rgb[((size_t)px + (size_t)py * C.width) * 3u + col % 3u] = s_rgb[e];
-        }
-      }
-    }
-  }
+  store_tile(C, T, k, color, s_rgb, s_px);
 
   // ray counters: one atomic per wavefront
   c_primary = wave_sum(c_primary);

@@ -69,9 +69,9 @@ __device__ __forceinline__ PixelRef pixel_ref(const RenderTarget& T, const DevCa
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t lx = (wave << 3) | (lane & 7u), ly = lane >> 3;
   p.in_range = k < T.n_local_tiles;
-  const uint32_t tile = k * T.world + T.rank;
-  p.x = (tile % T.tiles_x) * 32u + lx;
-  p.y = (tile / T.tiles_x) * 8u + ly;
+  const TileRef tr = tile_ref(T, k);
+  p.x = tr.tx * 32u + lx;
+  p.y = tr.ty * 8u + ly;
   p.valid = p.in_range && p.x < C.width && p.y < C.height;
   p.local = k * 256u + ly * 32u + lx;
   return p;
@@ -607,45 +607,6 @@ __device__ __forceinline__ V3 shade_hit(const DevScene& S, const DevCamera& C, c
   return surface;
 }
 
-// Framebuffer store of one 32x8 tile (local tile k), transposed through LDS so that every
-// wavefront writes whole 128-byte (RGBA8) / 384-byte (FP32 RGB) tile rows
-// (src/graphics.rs:44-46, 59-74).  All 256 threads of the workgroup call it.
-__device__ __forceinline__ void store_tile(const DevCamera& C, const RenderTarget& T, uint32_t k, V3 color, float* s_rgb,
-                                           uint32_t* s_px) {
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  const uint32_t lx = (wave << 3) | (lane & 7u), ly = lane >> 3;
-  const uint32_t slot = ly * 32u + lx;
-  s_rgb[slot * 3 + 0] = (float)color.x;
-  s_rgb[slot * 3 + 1] = (float)color.y;
-  s_rgb[slot * 3 + 2] = (float)color.z;
-  s_px[slot] = cast_u8(color.x) | (cast_u8(color.y) << 8) | (cast_u8(color.z) << 16) | 0xff000000u;
-  __syncthreads();
-  const uint32_t tile = k * T.world + T.rank;
-  const uint32_t tx = tile % T.tiles_x, ty = tile / T.tiles_x;
-  const uint32_t rx = threadIdx.x & 31u, ry = threadIdx.x >> 5;
-  const uint32_t gx = tx * 32u + rx, gy = ty * 8u + ry;
-  if (T.rgba8) {
-    uint32_t* out = reinterpret_cast<uint32_t*>(T.rgba8);
-    if (T.compact)
-      out[(size_t)k * 256u + threadIdx.x] = s_px[threadIdx.x];
-    else if (gx < C.width && gy < C.height)
-      out[(size_t)gx + (size_t)gy * C.width] = s_px[threadIdx.x];
-  }
-  if (T.rgb) {
-#pragma unroll
-    for (uint32_t pass = 0; pass < 3; ++pass) {
-      const uint32_t e = threadIdx.x + pass * 256u;
-      const uint32_t row = e / 96u, col = e % 96u;
-      if (T.compact) {
-        T.rgb[(size_t)k * 768u + e] = s_rgb[e];
-      } else {
-        const uint32_t fx = tx * 32u + col / 3u, fy = ty * 8u + row;
-        if (fx < C.width && fy < C.height) T.rgb[((size_t)fx + (size_t)fy * C.width) * 3u + col % 3u] = s_rgb[e];
-      }
-    }
-  }
-}
-
 // Kernel 3: shading and store from the hit records of the ray kernel(s).
 __global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, RenderTarget T, OpaqueBuffers B,
                                                       DevCounters* counters) {
@@ -708,36 +669,38 @@ hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCame
                                 const OpaqueBuffers& B, DevCounters* counters, hipEvent_t after_rays) {
   if (T.n_local_tiles == 0) return after_rays ? hipEventRecord(after_rays, st) : hipSuccess;
   const dim3 tiles(T.n_local_tiles), block(kBlock);
-  if (S.max_depth > 0) {
-    if (S.lights_uniform) {
-      // everything in one kernel; lights are swept in batches of 4 (the cluster levels cost next
-      // to nothing per batch, and 128 VGPRs hold the 4-light filter state without spills)
+  hipError_t e = hipSuccess;
+  if (S.max_depth > 0 && (S.lights_uniform || S.lights_bundled)) {
+    // everything in one kernel; lights are swept in batches of 4 (the cluster levels cost next
+    // to nothing per batch, and 128 VGPRs hold the 4-light filter state without spills).  Lights
+    // built from points (w == 1) add cones with their apex at the light.
+    if (S.lights_uniform)
       hipLaunchKernelGGL((render_uniform_kernel<4, true>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, counters);
-      return after_rays ? hipEventRecord(after_rays, st) : hipGetLastError();
-    } else if (S.lights_bundled) {
-      // some lights built from points (w == 1): same kernel with cones from those lights
+    else
       hipLaunchKernelGGL((render_uniform_kernel<4, false>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, counters);
-      return after_rays ? hipEventRecord(after_rays, st) : hipGetLastError();
-    } else {
-      hipLaunchKernelGGL(primary_kernel, tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);
-      switch (light_batch_for(S.n_lights)) {
-        case 1: hipLaunchKernelGGL((shadow_general_kernel<1>), tiles, block, 0, st, S, C, T, B, counters); break;
-        case 2: hipLaunchKernelGGL((shadow_general_kernel<2>), tiles, block, 0, st, S, C, T, B, counters); break;
-        case 4: hipLaunchKernelGGL((shadow_general_kernel<4>), tiles, block, 0, st, S, C, T, B, counters); break;
-        default: hipLaunchKernelGGL((shadow_general_kernel<8>), tiles, block, 0, st, S, C, T, B, counters); break;
-      }
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return after_rays ? hipEventRecord(after_rays, st) : hipSuccess;
+  }
+  if (S.max_depth > 0) {
+    hipLaunchKernelGGL(primary_kernel, tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, B, counters);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    switch (light_batch_for(S.n_lights)) {
+      case 1: hipLaunchKernelGGL((shadow_general_kernel<1>), tiles, block, 0, st, S, C, T, B, counters); break;
+      case 2: hipLaunchKernelGGL((shadow_general_kernel<2>), tiles, block, 0, st, S, C, T, B, counters); break;
+      case 4: hipLaunchKernelGGL((shadow_general_kernel<4>), tiles, block, 0, st, S, C, T, B, counters); break;
+      default: hipLaunchKernelGGL((shadow_general_kernel<8>), tiles, block, 0, st, S, C, T, B, counters); break;
     }
+    if ((e = hipGetLastError()) != hipSuccess) return e;
   } else {
     // MAX_DEPTH 0: trace_inner returns the ambient colour without intersecting anything
-    hipError_t e = hipMemsetAsync(B.hit_obj, 0xff, (size_t)T.n_local_tiles * 256u * sizeof(uint32_t), st);
-    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(B.hit_obj, 0xff, (size_t)T.n_local_tiles * 256u * sizeof(uint32_t), st)) != hipSuccess) return e;
   }
-  if (after_rays) {
-    hipError_t e = hipEventRecord(after_rays, st);
-    if (e != hipSuccess) return e;
-  }
+  if (after_rays && (e = hipEventRecord(after_rays, st)) != hipSuccess) return e;
   hipLaunchKernelGGL(shade_kernel, tiles, block, 0, st, S, C, T, B, counters);
   return hipGetLastError();
 }
+
+// Whether launch_render_opaque(S, ...) runs the three-kernel path and needs the per-pixel records of B.
+bool opaque_needs_records(const DevScene& S) { return !(S.max_depth > 0 && (S.lights_uniform || S.lights_bundled)); }
 
 }  // namespace rtk

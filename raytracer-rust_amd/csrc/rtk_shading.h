@@ -315,5 +315,51 @@ __device__ __forceinline__ V3 camera_ray_direction(const DevCamera& C, uint32_t 
   return {dv.x / mag, dv.y / mag, dv.z / mag};
 }
 
+// Framebuffer store of one 32x8 tile (local tile k), transposed through LDS so that every
+// wavefront writes whole 128-byte (RGBA8) / 384-byte (FP32 RGB) tile rows
+// (src/graphics.rs:44-46, 59-74).  All 256 threads of the workgroup call it; s_rgb holds 768
+// floats, s_px 256 words.  Three output layouts: the row-major frame; a rank's tile-major
+// compact buffer (tile mode); a rank's own tile rows one after the other, row-major at the
+// frame's width (band mode).
+__device__ __forceinline__ void store_tile(const DevCamera& C, const RenderTarget& T, uint32_t k, V3 color, float* s_rgb,
+                                           uint32_t* s_px) {
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t lx = (wave << 3) | (lane & 7u), ly = lane >> 3;
+  const uint32_t slot = ly * 32u + lx;
+  s_rgb[slot * 3 + 0] = (float)color.x;
+  s_rgb[slot * 3 + 1] = (float)color.y;
+  s_rgb[slot * 3 + 2] = (float)color.z;
+  s_px[slot] = cast_u8(color.x) | (cast_u8(color.y) << 8) | (cast_u8(color.z) << 16) | 0xff000000u;
+  __syncthreads();
+  // the tile's place is worked out again here (from a copy of k the optimiser cannot see through)
+  // rather than kept in scalar registers across the whole trace
+  const TileRef tr = tile_ref(T, k);
+  const bool tile_major = T.layout == 1u;
+  // first output row of this tile: its own in the frame, or its place among the rank's tile rows
+  const uint32_t out_row0 = (T.layout == 2u ? tr.lrow : tr.ty) * 8u;
+  const uint32_t rx = threadIdx.x & 31u, ry = threadIdx.x >> 5;
+  const uint32_t gx = tr.tx * 32u + rx, gy = tr.ty * 8u + ry;
+  if (T.rgba8) {
+    uint32_t* out = reinterpret_cast<uint32_t*>(T.rgba8);
+    if (tile_major)
+      out[(size_t)k * 256u + threadIdx.x] = s_px[threadIdx.x];
+    else if (gx < C.width && gy < C.height)
+      out[(size_t)gx + (size_t)(out_row0 + ry) * C.width] = s_px[threadIdx.x];
+  }
+  if (T.rgb) {
+#pragma unroll
+    for (uint32_t pass = 0; pass < 3; ++pass) {
+      const uint32_t e = threadIdx.x + pass * 256u;  // element of the tile's [8][96] float image
+      const uint32_t row = e / 96u, col = e % 96u;
+      if (tile_major) {
+        T.rgb[(size_t)k * 768u + e] = s_rgb[e];
+      } else {
+        const uint32_t fx = tr.tx * 32u + col / 3u, fy = tr.ty * 8u + row;
+        if (fx < C.width && fy < C.height) T.rgb[((size_t)fx + (size_t)(out_row0 + row) * C.width) * 3u + col % 3u] = s_rgb[e];
+      }
+    }
+  }
+}
+
 }  // namespace rtk
 #endif

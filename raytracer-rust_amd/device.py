@@ -33,6 +33,32 @@ def build_library(force=False):
 
 _lib = None
 
+class _OnStream:
+    """Queues library calls in order with torch's current stream.  A torch stream created by the
+    caller is handed over as it is.  torch reports its DEFAULT stream as handle 0, which the C ABI reads
+    as "the context's own stream" -- work queued there would not be ordered with what torch runs before
+    and after it -- so calls made under the default stream go to a side stream that first waits for the
+    default stream and that the default stream then waits for."""
+
+    def __init__(self, device):
+        self.device, self.current, self.side = device, None, None
+
+    def __enter__(self):
+        torch = self.device.torch
+        self.current = torch.cuda.current_stream(self.device.tdev)
+        if self.current.cuda_stream:
+            return C.c_void_p(self.current.cuda_stream)
+        if self.device.side_stream is None:
+            self.device.side_stream = torch.cuda.Stream(self.device.tdev)
+        self.side = self.device.side_stream
+        self.side.wait_stream(self.current)
+        return C.c_void_p(self.side.cuda_stream)
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.current.wait_stream(self.side)
+        return False
+
 
 def library():
     global _lib
@@ -95,6 +121,7 @@ class Device:
         self.torch = torch
         self.index = index
         self.tdev = torch.device("cuda", index)
+        self.side_stream = None  # see _OnStream
         ctx = C.c_void_p()
         _check(library().rtk_create(index, C.byref(ctx)))
         self.ctx = ctx
@@ -129,12 +156,35 @@ class Device:
         if want_rgba8:
             rgba = out_rgba8 if out_rgba8 is not None else torch.empty(shape4, dtype=torch.uint8, device=self.tdev)
         tiling = abi.rtk_tiling(rank, world)
-        stream = torch.cuda.current_stream(self.tdev).cuda_stream
-        _check(library().rtk_render_device(
-            self.ctx, handle.handle, C.byref(cam), C.byref(tiling),
-            C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
-            C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
-            C.c_void_p(stream)))
+        with _OnStream(self) as stream:
+            _check(library().rtk_render_device(
+                self.ctx, handle.handle, C.byref(cam), C.byref(tiling),
+                C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
+                C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
+                stream))
+        return rgb, rgba
+
+    def render_device_bands(self, handle, camera, rank=0, world=1, band_tile_rows=1, first_tile_row=0, n_tile_rows=0,
+                            compact=False, want_rgb=True, want_rgba8=True, out_rgb=None, out_rgba8=None):
+        """One rank of a band partition (whole tile rows dealt round-robin in bands of `band_tile_rows`).
+        compact=False: [H, W, 3] / [H, W, 4] frames of which only this rank's rows are written (pass the
+        frame every rank writes into as out_rgb / out_rgba8); compact=True: the rank's own rows only,
+        [rtk_band_pixel_rows, W, 3] / [.., W, 4]."""
+        torch = self.torch
+        cam = camera.to_abi() if hasattr(camera, "to_abi") else camera
+        bd = abi.rtk_banding(rank, world, band_tile_rows, first_tile_row, n_tile_rows, 1 if compact else 0)
+        rows = int(library().rtk_band_pixel_rows(cam.height, C.byref(bd))) if compact else cam.height
+        rgb = rgba = None
+        if want_rgb:
+            rgb = out_rgb if out_rgb is not None else torch.zeros((rows, cam.width, 3), dtype=torch.float32, device=self.tdev)
+        if want_rgba8:
+            rgba = out_rgba8 if out_rgba8 is not None else torch.zeros((rows, cam.width, 4), dtype=torch.uint8, device=self.tdev)
+        with _OnStream(self) as stream:
+            _check(library().rtk_render_device_bands(
+                self.ctx, handle.handle, C.byref(cam), C.byref(bd),
+                C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
+                C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
+                stream))
         return rgb, rgba
 
     def render_device_sampled(self, handle, camera, samples_per_axis, rank=0, world=1, want_rgb=True, want_rgba8=True,
@@ -156,12 +206,12 @@ class Device:
         if want_rgba8:
             rgba = out_rgba8 if out_rgba8 is not None else torch.empty(shape4, dtype=torch.uint8, device=self.tdev)
         tiling = abi.rtk_tiling(rank, world)
-        stream = torch.cuda.current_stream(self.tdev).cuda_stream
-        _check(library().rtk_render_device_sampled(
-            self.ctx, handle.handle, C.byref(cam), s, C.byref(tiling),
-            C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
-            C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
-            C.c_void_p(stream)))
+        with _OnStream(self) as stream:
+            _check(library().rtk_render_device_sampled(
+                self.ctx, handle.handle, C.byref(cam), s, C.byref(tiling),
+                C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
+                C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
+                stream))
         return rgb, rgba
 
     def resolve(self, samples, samples_per_axis):
@@ -175,9 +225,9 @@ class Device:
         h, w = samples.shape[0] // s, samples.shape[1] // s
         rgb = torch.empty((h, w, 3), dtype=torch.float32, device=self.tdev)
         rgba = torch.empty((h, w, 4), dtype=torch.uint8, device=self.tdev)
-        stream = torch.cuda.current_stream(self.tdev).cuda_stream
-        _check(library().rtk_resolve(self.ctx, w, h, s, C.c_void_p(samples.data_ptr()), C.c_void_p(rgb.data_ptr()),
-                                     C.c_void_p(rgba.data_ptr()), C.c_void_p(stream)))
+        with _OnStream(self) as stream:
+            _check(library().rtk_resolve(self.ctx, w, h, s, C.c_void_p(samples.data_ptr()), C.c_void_p(rgb.data_ptr()),
+                                         C.c_void_p(rgba.data_ptr()), stream))
         return rgb, rgba
 
     def stats(self):
@@ -227,21 +277,21 @@ class Device:
             rgb = out_rgb if out_rgb is not None else torch.empty((height, width, 3), dtype=torch.float32, device=self.tdev)
         if rgba8_compact is not None:
             rgba = out_rgba8 if out_rgba8 is not None else torch.empty((height, width, 4), dtype=torch.uint8, device=self.tdev)
-        stream = torch.cuda.current_stream(self.tdev).cuda_stream
         ptrs = (C.c_void_p(rgb_compact.data_ptr()) if rgb_compact is not None else None,
                 C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
                 C.c_void_p(rgba8_compact.data_ptr()) if rgba8_compact is not None else None,
-                C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
-                C.c_void_p(stream))
-        if samples_per_axis != 1:  # buffers of sampled, tiled renders: (32/s) x (8/s) tiles
-            rgb_stride = rank_stride_bytes if rank_stride_bytes is not None else slot_pixels * 12
-            px_stride = rank_stride_bytes if rank_stride_bytes is not None else slot_pixels * 4
-            _check(library().rtk_untile_sampled(self.ctx, width, height, int(samples_per_axis), world, rgb_stride, px_stride,
-                                                *ptrs))
-        elif rank_stride_bytes is None:
-            _check(library().rtk_untile(self.ctx, width, height, world, slot_pixels, *ptrs))
-        else:
-            _check(library().rtk_untile_strided(self.ctx, width, height, world, rank_stride_bytes, rank_stride_bytes, *ptrs))
+                C.c_void_p(rgba.data_ptr()) if rgba is not None else None)
+        with _OnStream(self) as stream:
+            if samples_per_axis != 1:  # buffers of sampled, tiled renders: (32/s) x (8/s) tiles
+                rgb_stride = rank_stride_bytes if rank_stride_bytes is not None else slot_pixels * 12
+                px_stride = rank_stride_bytes if rank_stride_bytes is not None else slot_pixels * 4
+                _check(library().rtk_untile_sampled(self.ctx, width, height, int(samples_per_axis), world, rgb_stride,
+                                                    px_stride, *ptrs, stream))
+            elif rank_stride_bytes is None:
+                _check(library().rtk_untile(self.ctx, width, height, world, slot_pixels, *ptrs, stream))
+            else:
+                _check(library().rtk_untile_strided(self.ctx, width, height, world, rank_stride_bytes, rank_stride_bytes,
+                                                    *ptrs, stream))
         return rgb, rgba
 
 

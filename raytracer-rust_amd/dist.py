@@ -292,9 +292,9 @@ def _render_compact(device, handle, cam, rank, world, out_rgb, out_rgba8):
 
     lib = _device.library()
     tiling = abi.rtk_tiling(rank, max(world, 1))
-    stream = device.torch.cuda.current_stream(device.tdev).cuda_stream
-    _device._check(lib.rtk_render_device(
-        device.ctx, handle.handle, C.byref(cam), C.byref(tiling),
-        C.c_void_p(out_rgb.data_ptr()) if out_rgb is not None else None,
-        C.c_void_p(out_rgba8.data_ptr()) if out_rgba8 is not None else None,
-        C.c_void_p(stream)))
+    with _device._OnStream(device) as stream:
+        _device._check(lib.rtk_render_device(
+            device.ctx, handle.handle, C.byref(cam), C.byref(tiling),
+            C.c_void_p(out_rgb.data_ptr()) if out_rgb is not None else None,
+            C.c_void_p(out_rgba8.data_ptr()) if out_rgba8 is not None else None,
+            stream))

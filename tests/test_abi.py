@@ -34,8 +34,9 @@ def test_struct_sizes_match_the_header_layout(rtk):
     assert C.sizeof(a.rtk_light) == 7 * 8
     assert C.sizeof(a.rtk_scene) == 8 + 8 + 8 + 8 + 24 + 8
     assert C.sizeof(a.rtk_camera) == 8 + 4 * 8 + 16 * 8
-    assert C.sizeof(a.rtk_stats) == 6 * 8
+    assert C.sizeof(a.rtk_stats) == 7 * 8
     assert C.sizeof(a.rtk_tiling) == 8
+    assert C.sizeof(a.rtk_banding) == 24
 
 
 def test_camera_init_equals_host_camera(rtk, lib):  # Camera::new, src/scene/cameras.rs:19-49
@@ -64,6 +65,32 @@ def test_tile_partition_counts(rtk, lib):
             tx, ty = dist.tile_grid(w, h)
             assert total == tx * ty
     assert lib.rtk_tiles_for_rank(64, 64, 2, 2) == 0 and lib.rtk_tiles_for_rank(64, 64, 0, 0) == 0
+
+
+def test_band_partition_counts(rtk, lib):
+    """Whole tile rows in bands of m, dealt round-robin: every tile row of the range has one owner."""
+    a = rtk.abi
+    for h in (1080, 2160, 9, 1, 37, 16384):
+        tiles_y = (h + 7) // 8
+        for world in (1, 2, 3, 8):
+            for m in (1, 2, 5, 64):
+                for first, n in ((0, 0), (min(3, tiles_y), 0), (0, min(4, tiles_y))):
+                    rows = n if n else tiles_y - first
+                    total = 0
+                    for rank in range(world):
+                        bd = a.rtk_banding(rank, world, m, first, n, 1)
+                        got = lib.rtk_band_tile_rows(h, C.byref(bd))
+                        want = sum(min(m, rows - b * m) for b in range(rank, (rows + m - 1) // m, world))
+                        assert got == want, (h, world, m, first, n, rank)
+                        assert lib.rtk_band_pixel_rows(h, C.byref(bd)) == 8 * got
+                        total += got
+                    assert total == rows
+    bad = a.rtk_banding(2, 2, 1, 0, 0, 0)
+    assert lib.rtk_band_tile_rows(64, C.byref(bad)) == 0
+    assert lib.rtk_band_tile_rows(64, C.byref(a.rtk_banding(0, 1, 0, 0, 0, 0))) == 0   # zero band height
+    assert lib.rtk_band_tile_rows(64, C.byref(a.rtk_banding(0, 1, 1, 9, 0, 0))) == 0   # starts below the frame
+    assert lib.rtk_band_tile_rows(64, C.byref(a.rtk_banding(0, 1, 1, 4, 5, 0))) == 0   # more rows than the frame has
+    assert lib.rtk_band_tile_rows(64, None) == 0
 
 
 def test_no_gpu_means_an_error_not_a_fallback(rtk, lib):

@@ -326,3 +326,157 @@ def test_example_script_reproduces_the_reference_image(tmp_path):
     meta = json.load(open(os.path.join(root, "tests", "golden", "output_meta.json")))
     assert hashlib.sha256(np.asarray(Image.open(out)).tobytes()).hexdigest() == meta["decoded_rgba_sha256"]
     assert "21939338 rays" in r.stdout
+
+
+def test_two_cameras_on_two_streams_do_not_mix(rtk, dev):
+    """Render calls of one context share the per-camera filter records and the counters; the library
+    orders a call behind the previous one when it arrives on another stream.  Two different views
+    queued back to back on two streams, several times over: every frame equals its serial render."""
+    import torch
+
+    scene, cam_a = rtk.synthetic.config("C3", 640, 360)
+    _, cam_b = rtk.synthetic.config("C3", 640, 360)
+    cam_b.transform = rtk.Matrix4x4.look_at(rtk.point(20, 9, -30), rtk.point(-5, 0, 25), rtk.vec3(0, 1, 0))
+    handle = dev.upload(scene)
+    want_a = dev.render_device(handle, cam_a)
+    want_b = dev.render_device(handle, cam_b)
+    torch.cuda.synchronize()
+    assert not torch.equal(want_a[1], want_b[1])
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(6):
+        with torch.cuda.stream(s1):
+            got_a = dev.render_device(handle, cam_a)
+        with torch.cuda.stream(s2):
+            got_b = dev.render_device(handle, cam_b)
+        with torch.cuda.stream(s1):
+            got_a2 = dev.render_device(handle, cam_a)
+        torch.cuda.synchronize()
+        for got, want in ((got_a, want_a), (got_b, want_b), (got_a2, want_a)):
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # the host-buffer call (context stream) right behind a device call on a torch stream
+    with torch.cuda.stream(s1):
+        got_b = dev.render_device(handle, cam_b)
+    canvas = dev.render(scene, cam_a)
+    torch.cuda.synchronize()
+    assert np.array_equal(canvas.rgba8, want_a[1].cpu().numpy()) and torch.equal(got_b[1], want_b[1])
+    handle.release()
+
+
+def _assemble_bands(dev, handle, camera, world, m, first=0, n=0, compact=True):
+    """Renders every rank's share of a band partition one after the other on this device and puts the
+    rows where a receiver would: returns (rgb, rgba8, summed rays)."""
+    import torch
+
+    lib = importlib.import_module("raytracer-rust_amd.device").library()
+    abi = importlib.import_module("raytracer-rust_amd.abi")
+    w, h = camera.width, camera.height
+    rgb = torch.zeros((h, w, 3), dtype=torch.float32, device=dev.tdev)
+    rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev.tdev)
+    tiles_y = (h + 7) // 8
+    rows = n if n else tiles_y - first
+    rays = 0
+    for rank in range(world):
+        if not compact:
+            dev.render_device_bands(handle, camera, rank, world, m, first, n, False, out_rgb=rgb, out_rgba8=rgba)
+            rays += dev.stats().rays
+            continue
+        c_rgb, c_rgba = dev.render_device_bands(handle, camera, rank, world, m, first, n, True)
+        rays += dev.stats().rays
+        bd = abi.rtk_banding(rank, world, m, first, n, 1)
+        assert c_rgb.shape[0] == lib.rtk_band_pixel_rows(h, C.byref(bd))
+        local = 0
+        for b in range(rank, (rows + m - 1) // m, world):
+            t0 = first + b * m
+            t1 = min(first + rows, t0 + m)
+            y0, y1 = t0 * 8, min(h, t1 * 8)
+            rgb[y0:y1] = c_rgb[local * 8: local * 8 + (y1 - y0)]
+            rgba[y0:y1] = c_rgba[local * 8: local * 8 + (y1 - y0)]
+            local += t1 - t0
+    return rgb, rgba, rays
+
+
+@pytest.mark.parametrize("name,w,h,world,m", [("C2", 480, 270, 2, 1), ("C2", 250, 131, 3, 2), ("C2g", 250, 131, 8, 1),
+                                              ("C3", 333, 200, 5, 4), ("C2", 64, 9, 4, 1)])
+def test_band_partition_is_bit_identical_to_single_rank(rtk, dev, name, w, h, world, m):
+    import torch
+
+    scene, camera = rtk.synthetic.config(name, w, h)
+    handle = dev.upload(scene)
+    rgb1, rgba1 = dev.render_device(handle, camera)
+    st1 = dev.stats()
+    for compact in (True, False):
+        rgb, rgba, rays = _assemble_bands(dev, handle, camera, world, m, compact=compact)
+        torch.cuda.synchronize()
+        assert torch.equal(rgb, rgb1) and torch.equal(rgba, rgba1), compact
+        assert rays == st1.rays
+    # a range of tile rows only: rows outside it stay untouched
+    tiles_y = (h + 7) // 8
+    if tiles_y >= 4:
+        first, n = 1, tiles_y - 2
+        rgb, rgba, _ = _assemble_bands(dev, handle, camera, world, m, first, n, compact=False)
+        torch.cuda.synchronize()
+        y0, y1 = first * 8, min(h, (first + n) * 8)
+        assert torch.equal(rgba[y0:y1], rgba1[y0:y1]) and torch.equal(rgb[y0:y1], rgb1[y0:y1])
+        assert int(rgba[:y0].max()) == 0 and (y1 >= h or int(rgba[y1:].max()) == 0)
+    handle.release()
+
+
+def test_band_partition_rejects_bad_arguments(rtk, dev, device_mod):
+    scene, camera = rtk.synthetic.config("C2", 64, 32)
+    handle = dev.upload(scene)
+    for args in ((2, 2, 1, 0, 0), (0, 1, 0, 0, 0), (0, 1, 1, 5, 0), (0, 1, 1, 2, 3)):
+        with pytest.raises(device_mod.RtkError) as e:
+            dev.render_device_bands(handle, camera, *args)
+        assert e.value.code == rtk.abi.RTK_ERR_INVALID
+    handle.release()
+
+
+@pytest.mark.parametrize("name,world", [("C4", 2), ("C4", 4), ("C4", 8), ("C4", 10), ("C5", 8)])
+def test_partitions_of_the_benchmark_frames_at_full_size(rtk, dev, name, world):
+    """BASELINE configurations 4 (3840x2160 over 2/4/8 ranks) and 5 (16384x16384 over 8) at their real
+    sizes: every rank's share rendered one after the other on this device, by tiles (the compact
+    buffers a gather carries, then the de-interleave kernel) and by bands (rows at their final place);
+    both frames equal the single-rank frame and the ray counts add up."""
+    import torch
+
+    dist = importlib.import_module("raytracer-rust_amd.dist")
+    scene, camera = rtk.synthetic.config(name)
+    w, h = camera.width, camera.height
+    want_rgb = name != "C5"  # the FP32 frame of configuration 5 is 3.2 GB, three copies of it add nothing
+    handle = dev.upload(scene)
+    rgb1, rgba1 = dev.render_device(handle, camera, want_rgb=want_rgb)
+    st1 = dev.stats()
+    # tiles dealt round-robin; per rank ONE message (its FP32 tiles, then its RGBA8 tiles), as the
+    # multi-process renderer gathers them -- also the layout of its virtual ranks when rank 0 takes a
+    # larger share (world 10 = 8 ranks of which rank 0 renders 3 shares)
+    slot = dist.slot_pixels(w, h, world)
+    rgb_bytes = slot * 12 if want_rgb else 0
+    message = torch.zeros((world, rgb_bytes + slot * 4), dtype=torch.uint8, device=dev.tdev)
+    rays = 0
+    for rank in range(world):
+        n = dist.tiles_for_rank(w, h, rank, world) * 256
+        rgb = message[rank, :rgb_bytes].view(torch.float32).view(slot, 3) if want_rgb else None
+        rgba = message[rank, rgb_bytes:].view(slot, 4)
+        dev.render_device(handle, camera, rank=rank, world=world, want_rgb=want_rgb,
+                          out_rgb=rgb[:n] if want_rgb else None, out_rgba8=rgba[:n])
+        rays += dev.stats().rays
+    rgb0 = message[0, :rgb_bytes].view(torch.float32).view(slot, 3) if want_rgb else None
+    rgba0 = message[0, rgb_bytes:].view(slot, 4)
+    f_rgb, f_rgba = dev.untile(w, h, world, slot, rgb0, rgba0, rank_stride_bytes=rgb_bytes + slot * 4)
+    torch.cuda.synchronize()
+    assert torch.equal(f_rgba, rgba1) and (not want_rgb or torch.equal(f_rgb, rgb1))
+    assert rays == st1.rays
+    del message, f_rgb, f_rgba
+    # bands of whole tile rows, written in place
+    tiles_y = (h + 7) // 8
+    m = max(1, tiles_y // (world * 32))
+    f_rgb = torch.zeros((h, w, 3), dtype=torch.float32, device=dev.tdev) if want_rgb else None
+    f_rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev.tdev)
+    rays = 0
+    for rank in range(world):
+        dev.render_device_bands(handle, camera, rank, world, m, want_rgb=want_rgb, out_rgb=f_rgb, out_rgba8=f_rgba)
+        rays += dev.stats().rays
+    torch.cuda.synchronize()
+    assert torch.equal(f_rgba, rgba1) and (not want_rgb or torch.equal(f_rgb, rgb1))
+    assert rays == st1.rays
+    handle.release()

@@ -214,6 +214,24 @@ int rtk_render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camer
 int rtk_render_device_bands(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera,
                             const rtk_banding* banding, float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream);
 
+/* rtk_render_device that allocates nothing.  It has no counterpart in the reference; it is for
+ * callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  Everything the kernels need beyond the scene, the camera
+ * and the outputs -- the per-camera filter records, the ray counters, and for scenes with a
+ * light whose w is neither 0 nor 1 the per-pixel hit records -- lives in a fixed array inside
+ * the library's device image (RTK_STATIC_SCRATCH_BYTES per GPU, held until the process ends)
+ * instead of memory of the scene handle and the context.  Same arguments, outputs and ray
+ * counts as rtk_render_device.  Limits (RTK_ERR_UNSUPPORTED beyond them): at most
+ * RTK_STATIC_MAX_SPHERES spheres in the scene; at most RTK_STATIC_MAX_RECORD_PIXELS pixels per
+ * call for scenes that need hit records (split larger frames with `tiling`).  Every call on a
+ * GPU, from whatever context, shares that GPU's array: calls that overlap on one GPU race.
+ * Calls of ONE context are ordered by the library like all its render calls. */
+#define RTK_STATIC_MAX_SPHERES 32768u
+#define RTK_STATIC_MAX_RECORD_PIXELS 131072u
+#define RTK_STATIC_SCRATCH_BYTES (3u << 20)
+int rtk_render_device_static(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera,
+                             const rtk_tiling* tiling, float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream);
+
 /* Same render with HOST output buffers (whole frame, row-major); uploads the scene,
  * renders, copies back and synchronises.  stats may be NULL.  The frame is rendered in
  * horizontal blocks and each block travels to the host while the next one renders. */

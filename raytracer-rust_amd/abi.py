@@ -28,6 +28,9 @@ RTK_TIMING_HISTORY = 64
 RTK_MAX_SAMPLES_PER_AXIS = 16
 RTK_TILE_W = 32
 RTK_TILE_H = 8
+RTK_STATIC_MAX_SPHERES = 32768
+RTK_STATIC_MAX_RECORD_PIXELS = 131072
+RTK_STATIC_SCRATCH_BYTES = 3 << 20
 
 Double3 = C.c_double * 3
 Double4 = C.c_double * 4
@@ -138,6 +141,10 @@ SYMBOLS = {
     "rtk_render_device_bands": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.POINTER(rtk_camera), C.POINTER(rtk_banding), C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "rtk_render_device_static": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.POINTER(rtk_camera), C.POINTER(rtk_tiling), C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "rtk_render": (
         C.c_int,

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -39,6 +40,54 @@ int fail_hip(hipError_t e, const char* what) {
 
 using rtk::fail;
 using rtk::fail_hip;
+
+// ---------------------------------------------------------------- static scratch (rtk_render_device_static)
+// Device memory that exists without any allocation call: one array per GPU inside the library's
+// code object.  Layout (offsets in bytes), sized by the limits in include/rtk.h:
+//   counters      kCounterShards x DevCounters
+//   prim          RTK_STATIC_MAX_SPHERES x float4     per-camera records of the per-ray filter
+//   prim_ball     RTK_STATIC_MAX_SPHERES x float4     ... of the wavefront-level cone test
+//   prim_cluster  RTK_STATIC_MAX_SPHERES / 64 x float4  ... of the cluster balls
+//   hit_t         RTK_STATIC_MAX_RECORD_PIXELS x f64  hit records of the three-kernel path
+//   hit_obj       RTK_STATIC_MAX_RECORD_PIXELS x u32
+//   shadow        RTK_STATIC_MAX_RECORD_PIXELS x u8
+namespace {
+constexpr size_t kStaticCounters = 0;
+constexpr size_t kStaticPrim = kStaticCounters + sizeof(rtk::DevCounters) * rtk::kCounterShards;
+constexpr size_t kStaticPrimBall = kStaticPrim + (size_t)RTK_STATIC_MAX_SPHERES * sizeof(float4);
+constexpr size_t kStaticPrimCluster = kStaticPrimBall + (size_t)RTK_STATIC_MAX_SPHERES * sizeof(float4);
+constexpr size_t kStaticHitT = kStaticPrimCluster + (size_t)RTK_STATIC_MAX_SPHERES / rtk::kBundle * sizeof(float4);
+constexpr size_t kStaticHitObj = kStaticHitT + (size_t)RTK_STATIC_MAX_RECORD_PIXELS * sizeof(double);
+constexpr size_t kStaticShadow = kStaticHitObj + (size_t)RTK_STATIC_MAX_RECORD_PIXELS * sizeof(uint32_t);
+constexpr size_t kStaticEnd = kStaticShadow + (size_t)RTK_STATIC_MAX_RECORD_PIXELS;
+static_assert(kStaticEnd <= RTK_STATIC_SCRATCH_BYTES, "static scratch layout exceeds RTK_STATIC_SCRATCH_BYTES");
+static_assert(kStaticPrim % 256 == 0 && kStaticHitT % 256 == 0 && kStaticHitObj % 256 == 0 && kStaticShadow % 256 == 0,
+              "pieces of the static scratch are 256-byte aligned");
+static_assert(RTK_STATIC_MAX_SPHERES % rtk::kBundle == 0, "the sphere limit is a whole number of clusters");
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[RTK_STATIC_SCRATCH_BYTES];
+
+namespace {
+// In host code the array's name is only a handle for the runtime: each GPU holds its own copy at
+// its own address, looked up once per device with that device current (rtk_create).
+constexpr int kMaxDevices = 64;
+unsigned char* g_static_scratch[kMaxDevices] = {};
+std::mutex g_static_mutex;
+
+hipError_t static_scratch_for_current_device(int device, unsigned char** out) {
+  std::lock_guard<std::mutex> lock(g_static_mutex);
+  if (!g_static_scratch[device]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_static_scratch[device] = (unsigned char*)p;
+  }
+  *out = g_static_scratch[device];
+  return hipSuccess;
+}
+}  // namespace
 
 namespace {
 
@@ -227,7 +276,8 @@ int rtk_create(int device_id, rtk_context** out) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) return fail(RTK_ERR_NO_DEVICE, "rtk_create: no HIP device available");
-  if (device_id < 0 || device_id >= count) return fail(RTK_ERR_NO_DEVICE, "rtk_create: device id out of range");
+  if (device_id < 0 || device_id >= count || device_id >= kMaxDevices)
+    return fail(RTK_ERR_NO_DEVICE, "rtk_create: device id out of range");
   hipDeviceProp_t prop;
   RTK_HIP(hipGetDeviceProperties(&prop, device_id));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -239,6 +289,7 @@ int rtk_create(int device_id, rtk_context** out) {
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = create_timing_events(ctx)) != hipSuccess ||
+      (e = static_scratch_for_current_device(device_id, &ctx->static_scratch)) != hipSuccess ||
       (e = hipMalloc((void**)&ctx->d_counters, sizeof(rtk::DevCounters) * rtk::kCounterShards)) != hipSuccess ||
       (e = hipMemset(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards)) != hipSuccess) {
     rtk_destroy(ctx);
@@ -908,6 +959,41 @@ int rtk_render_device_bands(rtk_context* ctx, rtk_scene_handle* scene, const rtk
   const int rc = rtk::partition_from_banding(camera, banding, p, "rtk_render_device_bands");
   if (rc != RTK_OK) return rc;
   return render_device(ctx, scene, camera, p, d_rgb_f32, d_rgba8, hip_stream, ResolveStep{});
+}
+
+int rtk_render_device_static(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, const rtk_tiling* tiling,
+                             float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream) {
+  const char* who = "rtk_render_device_static";
+  if (!ctx || !scene || !camera) return fail(RTK_ERR_INVALID, std::string(who) + ": null argument");
+  if (camera->width == 0 || camera->height == 0) return fail(RTK_ERR_INVALID, "camera has zero size");
+  rtk::Partition p;
+  int rc = rtk::partition_from_tiling(camera, tiling, p, who);
+  if (rc != RTK_OK) return rc;
+  const rtk::DevScene& S = scene->dev;
+  if (S.n_spheres_padded > RTK_STATIC_MAX_SPHERES)
+    return fail(RTK_ERR_UNSUPPORTED, std::string(who) + ": the scene has more than " + std::to_string(RTK_STATIC_MAX_SPHERES) +
+                                         " spheres (the limit of the static scratch); use rtk_render_device");
+  const bool records = !S.any_secondary && rtk::opaque_needs_records(S);
+  if (records && p.n_local_tiles * 256u > RTK_STATIC_MAX_RECORD_PIXELS)
+    return fail(RTK_ERR_UNSUPPORTED,
+                std::string(who) + ": this scene keeps a hit record per pixel and the call covers more than " +
+                    std::to_string(RTK_STATIC_MAX_RECORD_PIXELS) + " pixels; split the frame with `tiling` or use rtk_render_device");
+  unsigned char* base = ctx->static_scratch;  // this device's copy of the array, looked up in rtk_create
+  Scratch scr;
+  scr.counters = (rtk::DevCounters*)(base + kStaticCounters);
+  scr.prim = (float4*)(base + kStaticPrim);
+  scr.prim_ball = (float4*)(base + kStaticPrimBall);
+  scr.prim_cluster = (float4*)(base + kStaticPrimCluster);
+  if (records) {
+    scr.opaque.hit_t = (double*)(base + kStaticHitT);
+    scr.opaque.hit_obj = (uint32_t*)(base + kStaticHitObj);
+    scr.opaque.shadow = (uint8_t*)(base + kStaticShadow);
+  }
+  // from here on: stream waits, a memset of the counters, kernel launches and event records -- no allocation
+  Frame f;
+  if ((rc = frame_begin(f, ctx, scene, camera, hip_stream, scr)) != RTK_OK) return rc;
+  if ((rc = frame_launch(f, p, d_rgb_f32, d_rgba8, true)) != RTK_OK) return rc;
+  return frame_end(f, ResolveStep{}, nullptr);
 }
 
 int rtk_camera_supersample(const rtk_camera* camera, uint32_t s, rtk_camera* out) {

@@ -59,6 +59,7 @@ struct rtk_context {
   uint64_t n_timed = 0;                    // calls that recorded a triple; the newest sits in slot (n_timed - 1) % N
   rtk::DevCounters* d_counters = nullptr;
   rtk::DevCounters* last_counters = nullptr;  // where the last call counted its rays
+  unsigned char* static_scratch = nullptr;    // this device's copy of the library's static scratch array
   hipStream_t last_stream = nullptr;
   // staging for rtk_render (host-buffer variant)
   float* d_rgb = nullptr;

@@ -96,6 +96,9 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the renderer has no CPU path")
     torch.cuda.set_device(local_rank)
+    # frames are queued on a stream of their own: the library takes a real stream handle as it is, while
+    # work under torch's default stream would be handed over through a side stream, two event hops per frame
+    torch.cuda.set_stream(torch.cuda.Stream())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         tdist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -7,6 +7,7 @@
 #include "rtk_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -108,37 +109,36 @@ M4 m4_load(const double* p) {
   std::memcpy(m.e, p, sizeof m.e);
   return m;
 }
-// Laplace expansion along the first row of an n x n block held with row stride n, the way
-// the reference computes determinants (src/maths/matrices.rs:172-180, 256-264, 282-286).
-double det_n(const double* m, int n) {
-  if (n == 2) return m[0] * m[3] - m[1] * m[2];
+// Determinant of the 3x3 block of a 4x4 made of rows r[0..2] and columns c[0..2], by Laplace
+// expansion along its first row exactly as the reference computes determinants
+// (src/maths/matrices.rs:172-180, 256-264, 282-286): the sum starts at 0.0, every minor is
+// m[0]*m[3] - m[1]*m[2], odd terms enter with the minor negated.  Same operations in the same
+// order as the reference's recursion over copied sub-matrices, without the copies.
+inline double det3_of(const double* e, const int* r, const int* c) {
+  const double a0 = e[c[0] + 4 * r[0]], a1 = e[c[1] + 4 * r[0]], a2 = e[c[2] + 4 * r[0]];
+  const double a3 = e[c[0] + 4 * r[1]], a4 = e[c[1] + 4 * r[1]], a5 = e[c[2] + 4 * r[1]];
+  const double a6 = e[c[0] + 4 * r[2]], a7 = e[c[1] + 4 * r[2]], a8 = e[c[2] + 4 * r[2]];
+  const double m0 = a4 * a8 - a5 * a7, m1 = a3 * a8 - a5 * a6, m2 = a3 * a7 - a4 * a6;
   double result = 0.0;
-  double sub[9];
-  for (int i = 0; i < n; ++i) {
-    int k = 0;
-    for (int y = 1; y < n; ++y)
-      for (int x = 0; x < n; ++x)
-        if (x != i) sub[k++] = m[x + y * n];
-    double minor = det_n(sub, n - 1);
-    result += m[i] * ((i % 2 == 0) ? minor : -minor);
-  }
+  result += a0 * m0;
+  result += a1 * -m1;
+  result += a2 * m2;
   return result;
 }
-double cofactor4(const M4& m, int row, int col) {
-  double sub[9];
-  int k = 0;
-  for (int y = 0; y < 4; ++y)
-    for (int x = 0; x < 4; ++x)
-      if (y != row && x != col) sub[k++] = m.at(y, x);
-  double minor = det_n(sub, 3);
-  return ((row + col) % 2 == 0) ? minor : -minor;
-}
+constexpr int kOthers[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};  // the indices that are not i
 // Inverse by cofactors / determinant (src/maths/matrices.rs:183-198).  false = singular.
 bool m4_invert(const M4& m, M4& out) {
-  double det = det_n(m.e, 4);
+  double det = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    const double minor = det3_of(m.e, kOthers[0], kOthers[i]);
+    det += m.e[i] * ((i % 2 == 0) ? minor : -minor);
+  }
   if (det == 0.0) return false;
   for (int row = 0; row < 4; ++row)
-    for (int col = 0; col < 4; ++col) out.at(col, row) = cofactor4(m, row, col) / det;
+    for (int col = 0; col < 4; ++col) {
+      const double minor = det3_of(m.e, kOthers[row], kOthers[col]);
+      out.at(col, row) = (((row + col) % 2 == 0) ? minor : -minor) / det;
+    }
   return true;
 }
 bool is_affine(const double* t) { return t[12] == 0.0 && t[13] == 0.0 && t[14] == 0.0 && t[15] == 1.0; }
@@ -266,7 +266,9 @@ static hipError_t create_timing_events(rtk_context* ctx) {
       return e;
   }
   for (int i = 0; i < rtk_context::kHostBlocks; ++i)
-    if ((e = hipEventCreateWithFlags(&ctx->ev_block[i], hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&ctx->ev_block[i], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_landed[i], hipEventDisableTiming)) != hipSuccess)
+      return e;
   return hipSuccess;
 }
 
@@ -311,6 +313,8 @@ void rtk_destroy(rtk_context* ctx) {
   if (ctx->opaque.hit_t) (void)hipFree(ctx->opaque.hit_t);
   if (ctx->opaque.shadow) (void)hipFree(ctx->opaque.shadow);
   if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+  if (ctx->cached_handle) rtk_scene_release(ctx, ctx->cached_handle);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (int i = 0; i < RTK_TIMING_HISTORY; ++i) {
     if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
     if (ctx->ev_rays[i]) (void)hipEventDestroy(ctx->ev_rays[i]);
@@ -318,6 +322,9 @@ void rtk_destroy(rtk_context* ctx) {
   }
   for (hipEvent_t ev : ctx->ev_block)
     if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : ctx->ev_landed)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -370,10 +377,31 @@ static void cluster_order(std::vector<double4>& exact, std::vector<uint32_t>& ob
 
 static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& out);
 
+// Page-locked staging of a context, grown on demand: uploads copy from it at full PCIe rate and no
+// fresh pages are faulted in per scene.  Null when the allocation fails (the error text is set).
+static unsigned char* context_staging(void* user, size_t bytes) {
+  rtk_context* ctx = static_cast<rtk_context*>(user);
+  if (bytes > ctx->cap_stage) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr;
+    ctx->cap_stage = 0;
+    const size_t want = bytes + bytes / 4;
+    if (hipHostMalloc((void**)&ctx->h_stage, want, hipHostMallocDefault) != hipSuccess) {
+      ctx->h_stage = nullptr;
+      return nullptr;
+    }
+    ctx->cap_stage = want;
+  }
+  return ctx->h_stage;
+}
+
 int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle** out) {
   if (!ctx || !scene || !out) return fail(RTK_ERR_INVALID, "rtk_scene_upload: null argument");
   *out = nullptr;
   rtk::FlatScene flat;
+  flat.grow = context_staging;
+  flat.user = ctx;
   const int rc = rtk::flatten_scene(scene, flat);
   if (rc != RTK_OK) return rc;
   return rtk::place_scene(ctx, flat, out);
@@ -399,7 +427,23 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   if (scene->n_lights > 64) return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: more than 64 lights");
 
   using namespace rtk;
-  std::vector<DevObject> objects(scene->n_objects);
+  // Upper bound of the staged bytes (every piece rounded up to 256): the object array is built in
+  // place at its start, the smaller arrays are copied behind it once their sizes are known.
+  bool any_pattern = false;
+  for (uint32_t i = 0; i < scene->n_objects && !any_pattern; ++i) any_pattern = scene->objects[i].material.pattern_transformed != 0;
+  const size_t n_all = scene->n_objects, n_padded = n_all + kBundle, n_l = scene->n_lights;
+  const size_t bound = 16 * 256 + n_all * sizeof(DevObject) + n_l * (sizeof(DevLight) + sizeof(float4) + sizeof(uint32_t)) +
+                       n_padded * (3 * sizeof(float4) + sizeof(uint32_t)) + n_all * (sizeof(double4) + sizeof(uint32_t)) +
+                       (any_pattern ? n_all * 12 * sizeof(double) : 0) + ((n_l + 3) / 4) * n_padded * sizeof(float4) +
+                       (n_padded / kBundle + kBundle) * sizeof(float4);
+  if (flat.grow) {
+    flat.staged = flat.grow(flat.user, bound);
+  } else {
+    flat.own.reset(new unsigned char[bound]);
+    flat.staged = flat.own.get();
+  }
+  if (!flat.staged) return fail(RTK_ERR_NOMEM, "rtk_scene_upload: no staging memory");
+  DevObject* const objects = reinterpret_cast<DevObject*>(flat.staged);
   std::vector<DevLight> lights(scene->n_lights);
   std::vector<uint32_t> sph_object, plane_object;
   std::vector<double4> sph_exact;
@@ -408,8 +452,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
 
   // Per-object work (validation, the reference's cofactor inverse, bounding ball) is independent:
   // large scenes split it over a few host threads.  Errors are reported for the lowest object index.
-  for (uint32_t i = 0; i < scene->n_objects && pattern_inv.empty(); ++i)
-    if (scene->objects[i].material.pattern_transformed) pattern_inv.assign(12 * (size_t)scene->n_objects, 0.0);
+  if (any_pattern) pattern_inv.assign(12 * (size_t)scene->n_objects, 0.0);
   std::vector<double4> ball(scene->n_objects);
   struct Outcome {
     int status = RTK_OK;
@@ -491,8 +534,10 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
     track_n1 = track_n1 || oc.track_n1;
     any_secondary = any_secondary || oc.any_secondary;
   }
+  sph_object.reserve(n_padded);
+  sph_exact.reserve(n_all);
   for (uint32_t i = 0; i < scene->n_objects; ++i) {
-    if (scene->objects[i].kind == RTK_PLANE) {
+    if (objects[i].kind == RTK_PLANE) {
       plane_object.push_back(i);
     } else {
       sph_object.push_back(i);
@@ -645,7 +690,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
     if (src) sources.push_back({src, bytes, total});
     total += (bytes + 255u) & ~(size_t)255u;
   };
-  place(&rtk_scene_handle::d_objects, objects.data(), objects.size() * sizeof(DevObject));
+  place(&rtk_scene_handle::d_objects, nullptr, (size_t)scene->n_objects * sizeof(DevObject));  // already in place
   place(&rtk_scene_handle::d_lights, lights.data(), lights.size() * sizeof(DevLight));
   place(&rtk_scene_handle::d_filter, filter.data(), filter.size() * sizeof(float4));
   place(&rtk_scene_handle::d_exact, sph_exact.data(), sph_exact.size() * sizeof(double4));
@@ -663,8 +708,9 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   place(&rtk_scene_handle::d_prim_ball, nullptr, n_pad * sizeof(float4));
   place(&rtk_scene_handle::d_prim_cluster, nullptr, n_pad ? n_clusters_pad * sizeof(float4) : 0);
   flat.total = total;
-  flat.staged.assign(copied, 0);
-  for (const Source& p : sources) std::memcpy(flat.staged.data() + p.offset, p.src, p.bytes);
+  flat.staged_bytes = copied;
+  if (copied > bound) return fail(RTK_ERR_INVALID, "rtk_scene_upload: staging bound exceeded");  // cannot happen
+  for (const Source& p : sources) std::memcpy(flat.staged + p.offset, p.src, p.bytes);
 
   DevScene& d = flat.dev;
   d = DevScene{};
@@ -696,8 +742,8 @@ int rtk::place_scene(rtk_context* ctx, const rtk::FlatScene& flat, rtk_scene_han
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess && flat.total) {
     e = hipMalloc(&h->d_block, flat.total);
-    if (e == hipSuccess && !flat.staged.empty())
-      e = hipMemcpy(h->d_block, flat.staged.data(), flat.staged.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && flat.staged_bytes)
+      e = hipMemcpy(h->d_block, flat.staged, flat.staged_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess)
       for (const rtk::FlatScene::Piece& p : flat.pieces) h->*(p.dst) = (unsigned char*)h->d_block + p.offset;
   }
@@ -1115,22 +1161,62 @@ int rtk_render(rtk_context* ctx, const rtk_scene* scene, const rtk_camera* camer
   return rtk_render_sampled(ctx, scene, camera, 1, rgb_f32_out, rgba8_out, stats);
 }
 
+// Whether the device can write `p` directly (page-locked or registered host memory).  Ordinary
+// pageable memory makes hipMemcpyAsync stage and block; such buffers are filled through the
+// context's page-locked bounce buffer instead.
+static bool host_pointer_is_pinned(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // "invalid value" is the answer for pageable memory, not a failure
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeUnified;
+}
+
 // The frame of `camera` into host buffers, one sample per pixel: the frame is cut into blocks of
 // whole tile rows, rendered bottom-up on the context's stream; each block's rows start for the
 // host on the copy stream as soon as its kernel has finished, while the next block renders.
+// Pageable destinations receive their blocks from a page-locked bounce buffer, copied by a few
+// host threads as the blocks land.
 static int render_to_host(rtk_context* ctx, rtk_scene_handle* h, const rtk_camera* camera, float* rgb_f32_out,
                           uint8_t* rgba8_out) {
   const uint32_t width = camera->width, height = camera->height;
+  const size_t pixels = (size_t)width * height;
   const uint32_t rows = tiles_down(height);
-  const uint32_t n_blocks = (uint64_t)width * height >= (1u << 20) ? std::min<uint32_t>(rtk_context::kHostBlocks, rows) : 1u;
+  // about a million pixels per block: enough tiles per launch to fill the GPU several times over
+  const uint32_t n_blocks =
+      std::max<uint32_t>(1u, std::min<uint32_t>({(uint32_t)std::min<size_t>((pixels + (1u << 19)) >> 20, 1u << 20),
+                                                 (uint32_t)rtk_context::kHostBlocks, rows}));
   const uint32_t per_block = (rows + n_blocks - 1) / n_blocks;
   Scratch scr;
   int rc = context_scratch(ctx, h, (size_t)per_block * tiles_across(width) * 256u, scr);
   if (rc != RTK_OK) return rc;
+  // bounce buffer: FP32 part first, RGBA8 part behind it
+  const bool bounce_rgb = rgb_f32_out && !host_pointer_is_pinned(rgb_f32_out);
+  const bool bounce_px = rgba8_out && !host_pointer_is_pinned(rgba8_out);
+  if (bounce_rgb || bounce_px) {
+    RTK_HIP(hipSetDevice(ctx->device));
+    const size_t need = pixels * 16u;
+    if (need > ctx->cap_bounce) {
+      if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
+      ctx->h_bounce = nullptr;
+      ctx->cap_bounce = 0;
+      RTK_HIP(hipHostMalloc((void**)&ctx->h_bounce, need, hipHostMallocDefault));
+      ctx->cap_bounce = need;
+    }
+  }
+  float* const land_rgb = bounce_rgb ? reinterpret_cast<float*>(ctx->h_bounce) : rgb_f32_out;
+  uint8_t* const land_px = bounce_px ? ctx->h_bounce + pixels * 12u : rgba8_out;
+
   Frame f;
   if ((rc = frame_begin(f, ctx, h, camera, nullptr, scr)) != RTK_OK) return rc;
   float* d_rgb = rgb_f32_out ? ctx->d_rgb : nullptr;
   uint8_t* d_rgba8 = rgba8_out ? ctx->d_rgba8 : nullptr;
+  struct Block {
+    size_t first, count;  // pixels
+  };
+  Block blocks[rtk_context::kHostBlocks] = {};
+  uint32_t n_queued = 0;
   for (uint32_t i = 0; i < n_blocks; ++i) {
     const uint32_t b = n_blocks - 1u - i;  // bottom block first
     const uint32_t row_a = b * per_block, row_b = std::min(rows, row_a + per_block);
@@ -1139,19 +1225,95 @@ static int render_to_host(rtk_context* ctx, rtk_scene_handle* h, const rtk_camer
     rtk::Partition p;
     if ((rc = rtk::partition_from_banding(camera, &bd, p, "rtk_render")) != RTK_OK) return rc;
     if ((rc = frame_launch(f, p, d_rgb, d_rgba8, n_blocks == 1u)) != RTK_OK) return rc;
-    RTK_HIP(hipEventRecord(ctx->ev_block[i], f.st));
-    RTK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_block[i], 0));
+    RTK_HIP(hipEventRecord(ctx->ev_block[n_queued], f.st));
+    RTK_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_block[n_queued], 0));
     const size_t y0 = (size_t)row_a * RTK_TILE_H, y1 = std::min<size_t>(height, (size_t)row_b * RTK_TILE_H);
     const size_t first = y0 * width, count = (y1 - y0) * width;
     if (rgb_f32_out)
-      RTK_HIP(hipMemcpyAsync(rgb_f32_out + first * 3, d_rgb + first * 3, count * 3 * sizeof(float), hipMemcpyDeviceToHost,
+      RTK_HIP(hipMemcpyAsync(land_rgb + first * 3, d_rgb + first * 3, count * 3 * sizeof(float), hipMemcpyDeviceToHost,
                              ctx->copy_stream));
     if (rgba8_out)
-      RTK_HIP(hipMemcpyAsync(rgba8_out + first * 4, d_rgba8 + first * 4, count * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
+      RTK_HIP(hipMemcpyAsync(land_px + first * 4, d_rgba8 + first * 4, count * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
+    RTK_HIP(hipEventRecord(ctx->ev_landed[n_queued], ctx->copy_stream));
+    blocks[n_queued++] = {first, count};
   }
   if ((rc = frame_end(f, ResolveStep{}, nullptr)) != RTK_OK) return rc;
+
+  hipError_t worker_error = hipSuccess;
+  if (bounce_rgb || bounce_px) {
+    // host threads take pieces of the blocks in turn (a block is cut into kPieces so that the last
+    // block to land is not one thread's job): wait until the block has landed, copy the piece
+    constexpr uint32_t kPieces = 4;
+    const uint32_t hw = std::thread::hardware_concurrency();
+    const uint32_t n_threads = std::max(1u, std::min({n_queued * kPieces, 8u, hw ? hw : 1u}));
+    std::atomic<uint32_t> next{0};
+    std::atomic<int> first_error{(int)hipSuccess};
+    auto work = [&]() {
+      (void)hipSetDevice(ctx->device);
+      for (uint32_t item = next.fetch_add(1); item < n_queued * kPieces; item = next.fetch_add(1)) {
+        const uint32_t k = item / kPieces, piece = item % kPieces;
+        const hipError_t e = hipEventSynchronize(ctx->ev_landed[k]);
+        if (e != hipSuccess) {
+          int expected = (int)hipSuccess;
+          first_error.compare_exchange_strong(expected, (int)e);
+          continue;
+        }
+        const size_t a = blocks[k].first + blocks[k].count * piece / kPieces;
+        const size_t n = blocks[k].first + blocks[k].count * (piece + 1) / kPieces - a;
+        if (bounce_rgb) std::memcpy(rgb_f32_out + a * 3, land_rgb + a * 3, n * 12u);
+        if (bounce_px) std::memcpy(rgba8_out + a * 4, land_px + a * 4, n * 4u);
+      }
+    };
+    std::vector<std::thread> pool;
+    try {
+      pool.reserve(n_threads);
+      for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    } catch (...) {  // fewer threads than hoped for: the ones that started and this one do the work
+    }
+    work();
+    for (std::thread& t : pool) t.join();
+    worker_error = (hipError_t)first_error.load();
+  }
   RTK_HIP(hipStreamSynchronize(ctx->copy_stream));
   RTK_HIP(hipStreamSynchronize(ctx->stream));
+  if (worker_error != hipSuccess) return fail_hip(worker_error, "rtk_render: waiting for a block of the frame");
+  return RTK_OK;
+}
+
+// The device copy of `scene` for rtk_render: the one kept from the previous call when the caller
+// passes the same scene again (same counts, byte-identical objects and lights), else a fresh upload
+// that replaces it.  The handle belongs to the context.
+static int cached_scene(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle** out) {
+  if ((scene->n_objects && !scene->objects) || (scene->n_lights && !scene->lights))
+    return fail(RTK_ERR_INVALID, "rtk_scene_upload: null object or light array");
+  const rtk_scene& c = ctx->cached_scene;
+  if (ctx->cached_handle && c.n_objects == scene->n_objects && c.n_lights == scene->n_lights && c.max_depth == scene->max_depth &&
+      std::memcmp(c.ambient_color, scene->ambient_color, sizeof c.ambient_color) == 0 &&
+      (scene->n_objects == 0 ||
+       std::memcmp(ctx->cached_objects.data(), scene->objects, (size_t)scene->n_objects * sizeof(rtk_object)) == 0) &&
+      (scene->n_lights == 0 ||
+       std::memcmp(ctx->cached_lights.data(), scene->lights, (size_t)scene->n_lights * sizeof(rtk_light)) == 0)) {
+    *out = ctx->cached_handle;
+    return RTK_OK;
+  }
+  if (ctx->cached_handle) {
+    // the previous frame of that scene was synchronised before rtk_render returned
+    rtk_scene_release(ctx, ctx->cached_handle);
+    ctx->cached_handle = nullptr;
+  }
+  rtk_scene_handle* h = nullptr;
+  const int rc = rtk_scene_upload(ctx, scene, &h);
+  if (rc != RTK_OK) return rc;
+  try {
+    ctx->cached_objects.assign(scene->objects, scene->objects + scene->n_objects);
+    ctx->cached_lights.assign(scene->lights, scene->lights + scene->n_lights);
+    ctx->cached_scene = *scene;
+    ctx->cached_handle = h;
+  } catch (const std::bad_alloc&) {
+    rtk_scene_release(ctx, h);
+    return fail(RTK_ERR_NOMEM, "rtk_render: out of host memory");
+  }
+  *out = h;
   return RTK_OK;
 }
 
@@ -1162,7 +1324,7 @@ int rtk_render_sampled(rtk_context* ctx, const rtk_scene* scene, const rtk_camer
     return fail(RTK_ERR_INVALID, "rtk_render_sampled: samples_per_axis must be 1.." + std::to_string(RTK_MAX_SAMPLES_PER_AXIS));
   if (camera->width == 0 || camera->height == 0) return fail(RTK_ERR_INVALID, "camera has zero size");
   rtk_scene_handle* h = nullptr;
-  int rc = rtk_scene_upload(ctx, scene, &h);
+  int rc = cached_scene(ctx, scene, &h);
   if (rc != RTK_OK) return rc;
   const size_t pixels = (size_t)camera->width * camera->height;
   if (pixels > ctx->cap_pixels) {
@@ -1173,10 +1335,7 @@ int rtk_render_sampled(rtk_context* ctx, const rtk_scene* scene, const rtk_camer
     ctx->cap_pixels = 0;
     hipError_t e = hipMalloc((void**)&ctx->d_rgb, pixels * 3 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_rgba8, pixels * 4);
-    if (e != hipSuccess) {
-      rtk_scene_release(ctx, h);
-      return fail_hip(e, "rtk_render: framebuffer allocation");
-    }
+    if (e != hipSuccess) return fail_hip(e, "rtk_render: framebuffer allocation");
     ctx->cap_pixels = pixels;
   }
   if (samples_per_axis == 1) {
@@ -1193,7 +1352,6 @@ int rtk_render_sampled(rtk_context* ctx, const rtk_scene* scene, const rtk_camer
     if (rc == RTK_OK && e != hipSuccess) rc = fail_hip(e, "rtk_render: copy back");
   }
   if (rc == RTK_OK && stats) rc = rtk_get_stats(ctx, stats);
-  rtk_scene_release(ctx, h);
   return rc;
 }
 

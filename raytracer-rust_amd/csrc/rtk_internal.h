@@ -8,6 +8,7 @@
 #include "rtk_device.h"
 #include "rtk_kernels.h"
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -65,11 +66,23 @@ struct rtk_context {
   float* d_rgb = nullptr;
   uint8_t* d_rgba8 = nullptr;
   size_t cap_pixels = 0;
-  static constexpr int kHostBlocks = 8;  // blocks a frame is cut into by rtk_render
-  hipEvent_t ev_block[kHostBlocks] = {};
+  static constexpr int kHostBlocks = 16;  // blocks a frame is cut into by rtk_render
+  hipEvent_t ev_block[kHostBlocks] = {};   // a block's kernels have finished
+  hipEvent_t ev_landed[kHostBlocks] = {};  // ... and its rows have arrived in host memory
+  unsigned char* h_bounce = nullptr;       // page-locked landing area for pageable destinations (grown on demand)
+  size_t cap_bounce = 0;
   // intermediate records of the three-kernel path (grown on demand, kept for the next frame)
   rtk::OpaqueBuffers opaque{};
   size_t cap_opaque = 0;
+  // page-locked staging for scene uploads (grown on demand)
+  unsigned char* h_stage = nullptr;
+  size_t cap_stage = 0;
+  // the scene of the last rtk_render call, kept on the device: a caller that renders the same scene
+  // again (another camera, another frame size) skips flattening and upload
+  std::vector<rtk_object> cached_objects;
+  std::vector<rtk_light> cached_lights;
+  rtk_scene cached_scene{};
+  rtk_scene_handle* cached_handle = nullptr;
   // sample frame of rtk_render_device_sampled (grown on demand)
   float* d_samples = nullptr;
   size_t cap_samples = 0;  // in samples
@@ -85,9 +98,15 @@ struct FlatScene {
     size_t bytes, offset;
   };
   std::vector<Piece> pieces;
-  std::vector<unsigned char> staged;  // the first `staged.size()` bytes of the allocation
-  size_t total = 0;                   // allocation size (the per-camera records follow the staged part)
+  unsigned char* staged = nullptr;  // the first `staged_bytes` bytes of the allocation
+  size_t staged_bytes = 0;
+  size_t total = 0;                 // allocation size (the per-camera records follow the staged part)
   DevScene dev{};
+  // Where the staged bytes live: memory from `grow` (e.g. a context's page-locked staging buffer,
+  // which must hold at least the asked-for bytes until the scene has been placed), else `own`.
+  unsigned char* (*grow)(void* user, size_t bytes) = nullptr;
+  void* user = nullptr;
+  std::unique_ptr<unsigned char[]> own;
 };
 // Validation and flattening (host work only); RTK_OK or an rtk_status with the error text set.
 int flatten_scene(const rtk_scene* scene, FlatScene& out);

@@ -480,3 +480,55 @@ def test_partitions_of_the_benchmark_frames_at_full_size(rtk, dev, name, world):
     assert torch.equal(f_rgba, rgba1) and (not want_rgb or torch.equal(f_rgb, rgb1))
     assert rays == st1.rays
     handle.release()
+
+
+@pytest.mark.parametrize("name,w,h", [("C2", 1920, 1080), ("C3", 1283, 1021), ("C2g", 300, 200)])
+def test_host_render_into_pageable_and_pinned_buffers(rtk, dev, device_mod, name, w, h):
+    """rtk_render renders large frames block by block and copies each block while the next one renders;
+    ordinary (pageable) destinations go through the library's page-locked bounce buffer and host copy
+    threads.  Same frame either way, equal to the device render; one output alone works too; calling
+    again with the same scene reuses the device copy, a changed scene replaces it."""
+    import torch
+
+    lib = device_mod.library()
+    scene, camera = rtk.synthetic.config(name, w, h)
+    s, cam = scene.to_abi(), camera.to_abi()
+    handle = dev.upload(scene)
+    want_rgb, want_rgba = dev.render_device(handle, camera)
+    want_st = dev.stats()
+    torch.cuda.synchronize()
+    want_rgb, want_rgba = want_rgb.cpu().numpy(), want_rgba.cpu().numpy()
+
+    def call(rgb, rgba, scene_abi=s):
+        st = rtk.abi.rtk_stats()
+        device_mod._check(lib.rtk_render(dev.ctx, C.byref(scene_abi), C.byref(cam),
+                                         rgb.ctypes.data_as(C.c_void_p) if rgb is not None else None,
+                                         rgba.ctypes.data_as(C.c_void_p) if rgba is not None else None, C.byref(st)))
+        return st
+
+    pinned = (torch.zeros((h, w, 3), dtype=torch.float32, pin_memory=True).numpy(),
+              torch.zeros((h, w, 4), dtype=torch.uint8, pin_memory=True).numpy())
+    pageable = (np.zeros((h, w, 3), np.float32), np.zeros((h, w, 4), np.uint8))
+    for rgb, rgba in (pinned, pageable, (pageable[0], pinned[1])):
+        rgb[:] = 0
+        rgba[:] = 0
+        st = call(rgb, rgba)
+        assert np.array_equal(rgb, want_rgb) and np.array_equal(rgba, want_rgba)
+        assert st.rays_primary + st.rays_shadow + st.rays_secondary == want_st.rays
+    only = np.zeros((h, w, 4), np.uint8)
+    call(None, only)
+    assert np.array_equal(only, want_rgba)
+    only = np.zeros((h, w, 3), np.float32)
+    call(only, None)
+    assert np.array_equal(only, want_rgb)
+    # a changed scene is not served from the copy of the previous one
+    s2 = scene.to_abi()
+    s2.objects[0].material.color_a[0] = 0.123  # the floor's first colour
+    s2.objects[0].material.color_a[1] = 0.9
+    rgba2 = np.zeros((h, w, 4), np.uint8)
+    call(None, rgba2, s2)
+    assert not np.array_equal(rgba2, want_rgba)
+    rgba3 = np.zeros((h, w, 4), np.uint8)
+    call(None, rgba3)  # and back
+    assert np.array_equal(rgba3, want_rgba)
+    handle.release()

@@ -38,7 +38,8 @@ typedef enum rtk_status {
   RTK_ERR_UNSUPPORTED = -3,     /* input outside the supported envelope (see below)    */
   RTK_ERR_HIP = -4,             /* a HIP runtime call failed                           */
   RTK_ERR_NO_DEVICE = -5,       /* no gfx950 device / library built without a kernel   */
-  RTK_ERR_NOMEM = -6
+  RTK_ERR_NOMEM = -6,
+  RTK_ERR_RCCL = -7             /* librccl could not be loaded, or an RCCL call failed */
 } rtk_status;
 
 /* Shape kinds: `PackedKind` (src/loader.rs:52-57). */
@@ -312,6 +313,41 @@ int rtk_get_stats(rtk_context* ctx, rtk_stats* stats);
  * filled (or an rtk_status < 0).  No counterpart in the reference. */
 #define RTK_TIMING_HISTORY 64
 int rtk_get_timing_history(rtk_context* ctx, uint32_t capacity, double* kernel_ms, double* rays_ms);
+
+/* ---- One frame over several GPUs of one node, from ONE process.  No counterpart in the
+ * reference (its loop is single-threaded, src/scene/cameras.rs:75-82); pixels are independent,
+ * so the frame shards with no data-path collective.  Member r of the group renders the bands
+ * (rtk_banding, world = n_members) dealt to r; member 0 (the root) writes its rows straight
+ * into the caller's frame, every other member renders into a band buffer of its own and sends
+ * each band with ncclSend; the root posts the matching ncclRecv with the band's final rows in
+ * the caller's frame as the target, so nothing is staged or de-interleaved on the root.  One
+ * RCCL communicator per distinct device (ncclCommInitAll), all sends and receives of a frame
+ * in one ncclGroupStart / ncclGroupEnd.  Two frames may be in flight: the members' band
+ * buffers alternate, so the exchange of frame k overlaps the render of frame k + 1.
+ *
+ * device_ids may name a device more than once: such members share that device's communicator
+ * and exchange through RCCL's send-to-self, which lets a one-GPU machine run every step of the
+ * multi-GPU frame.  librccl.so.1 is loaded when the first group is created; a group of one
+ * member needs no exchange and does not load it. */
+typedef struct rtk_group rtk_group;
+int rtk_group_create(const int* device_ids, int n_members, rtk_group** out);
+void rtk_group_destroy(rtk_group* group);
+int rtk_group_size(const rtk_group* group);
+/* Flattens the scene once and copies it to every member's device (replacing the group's
+ * previous scene, if any). */
+int rtk_group_upload(rtk_group* group, const rtk_scene* scene);
+/* Renders one frame into DEVICE buffers on the root's device (device_ids[0]); either may be
+ * NULL.  hip_stream: a stream of the root's device, or NULL for the root context's own.
+ * Asynchronous: when the call returns the frame is queued, and hip_stream has been made to
+ * wait for all of it (the root's own rows and every received band).  A caller that keeps two
+ * frames in flight alternates two output buffers. */
+int rtk_group_render_device(rtk_group* group, const rtk_camera* camera, float* d_rgb_f32, uint8_t* d_rgba8,
+                            void* hip_stream);
+/* Waits for the last frame and returns its ray counts summed over the members, the slowest
+ * member's kernel times, and gather_ms. */
+int rtk_group_get_stats(rtk_group* group, rtk_stats* stats);
+/* Tile rows per band the group uses for a frame of `height` pixel rows. */
+uint32_t rtk_group_band_tile_rows(const rtk_group* group, uint32_t height);
 
 /* Thread-local description of the last failure on this thread ("" if none). */
 const char* rtk_last_error(void);

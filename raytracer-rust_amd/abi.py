@@ -12,6 +12,7 @@ RTK_ERR_UNSUPPORTED = -3
 RTK_ERR_HIP = -4
 RTK_ERR_NO_DEVICE = -5
 RTK_ERR_NOMEM = -6
+RTK_ERR_RCCL = -7
 
 RTK_SPHERE = 0
 RTK_PLANE = 1
@@ -184,6 +185,13 @@ SYMBOLS = {
     ),
     "rtk_get_stats": (C.c_int, [C.c_void_p, C.POINTER(rtk_stats)]),
     "rtk_get_timing_history": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rtk_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "rtk_group_destroy": (None, [C.c_void_p]),
+    "rtk_group_size": (C.c_int, [C.c_void_p]),
+    "rtk_group_upload": (C.c_int, [C.c_void_p, C.POINTER(rtk_scene)]),
+    "rtk_group_render_device": (C.c_int, [C.c_void_p, C.POINTER(rtk_camera), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtk_group_get_stats": (C.c_int, [C.c_void_p, C.POINTER(rtk_stats)]),
+    "rtk_group_band_tile_rows": (C.c_uint32, [C.c_void_p, C.c_uint32]),
     "rtk_last_error": (C.c_char_p, []),
     "rtk_version": (C.c_char_p, []),
 }

@@ -753,19 +753,19 @@ int rtk::place_scene(rtk_context* ctx, const rtk::FlatScene& flat, rtk_scene_han
   }
   rtk::DevScene& d = h->dev;
   d = flat.dev;
-  d.objects = (const rtk::DevObject*)h->d_objects;
-  d.lights = (const rtk::DevLight*)h->d_lights;
-  d.sph_filter = (const float4*)h->d_filter;
-  d.sph_exact = (const double4*)h->d_exact;
-  d.sph_object = (const uint32_t*)h->d_sph_object;
-  d.plane_object = (const uint32_t*)h->d_plane_object;
-  d.pattern_inv = (const double*)h->d_pattern_inv;
-  d.light_filter = (const float4*)h->d_light_filter;
-  d.light_kind = (const uint32_t*)h->d_light_kind;
-  d.k_table = (const float4*)h->d_k_table;
-  d.sph_tab = (const float4*)h->d_sph_tab;
-  d.sph_ball = (const float4*)h->d_sph_ball;
-  d.cluster_ball = (const float4*)h->d_cluster_ball;
+  d.objects = (decltype(d.objects))h->d_objects;
+  d.lights = (decltype(d.lights))h->d_lights;
+  d.sph_filter = (decltype(d.sph_filter))h->d_filter;
+  d.sph_exact = (decltype(d.sph_exact))h->d_exact;
+  d.sph_object = (decltype(d.sph_object))h->d_sph_object;
+  d.plane_object = (decltype(d.plane_object))h->d_plane_object;
+  d.pattern_inv = (decltype(d.pattern_inv))h->d_pattern_inv;
+  d.light_filter = (decltype(d.light_filter))h->d_light_filter;
+  d.light_kind = (decltype(d.light_kind))h->d_light_kind;
+  d.k_table = (decltype(d.k_table))h->d_k_table;
+  d.sph_tab = (decltype(d.sph_tab))h->d_sph_tab;
+  d.sph_ball = (decltype(d.sph_ball))h->d_sph_ball;
+  d.cluster_ball = (decltype(d.cluster_ball))h->d_cluster_ball;
   *out = h;
   return RTK_OK;
 }

@@ -44,20 +44,33 @@ struct DevLight {
 // Both arrays (and sph_object) are padded to a multiple of kBundle by repeating the last
 // real record; testing a sphere twice changes no decision.  The one-ray-per-lane sweeps stop
 // at n_spheres_grouped.
+// The record arrays of a scene are read-only for every kernel that sees a DevScene.  In device
+// code their pointers carry the constant address space: a load through one whose address is the
+// same in every lane (an index taken from a ballot, a loop counter) then becomes a scalar load --
+// the record arrives in scalar registers, through the scalar cache, and costs no vector
+// registers; without the qualifier the compiler cannot prove the memory unwritten and issues a
+// 64-lane vector load of one address.  Loads with per-lane addresses are vector loads either way.
+// Same pointer size and value on both sides, so host and device agree on the layout.
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+#define RTK_RO __attribute__((address_space(4)))
+#else
+#define RTK_RO
+#endif
+
 struct DevScene {
-  const DevObject* objects;
-  const DevLight* lights;
-  const float4* sph_filter;
-  const double4* sph_exact;     // centre (world, f64) and bounding radius per filter record
-  const uint32_t* sph_object;   // filter record -> object index
-  const uint32_t* plane_object; // plane list -> object index
-  const double* pattern_inv;    // per object, rows 0..2 of the inverse pattern transform (12 f64); null when no pattern has one
-  const float4* light_filter;   // per light: w = 0: unit line direction g = L/|L| and rho = -1/|L|; w = 1: position minus DevScene::center
-  const uint32_t* light_kind;   // per light: 0 (w == 0), 1 (w == 1), 2 (anything else)
-  const float4* k_table;        // [batch][sphere][k_width]: c_j.g_k - R_j'^2 rho_k, only when lights_uniform
-  const float4* sph_tab;        // {cx, cy, cz, kappa |c|^2 - R'^2}: sphere record of the tabulated shadow filter
-  const float4* sph_ball;       // {cx, cy, cz, R'}: record of the wavefront-level test; padding has R' = -1e30
-  const float4* cluster_ball;   // one ball around each aligned run of kBundle spheres; padded to kBundle with R = -1e30
+  const RTK_RO DevObject* objects;
+  const RTK_RO DevLight* lights;
+  const RTK_RO float4* sph_filter;
+  const RTK_RO double4* sph_exact;     // centre (world, f64) and bounding radius per filter record
+  const RTK_RO uint32_t* sph_object;   // filter record -> object index
+  const RTK_RO uint32_t* plane_object; // plane list -> object index
+  const RTK_RO double* pattern_inv;    // per object, rows 0..2 of the inverse pattern transform (12 f64); null when no pattern has one
+  const RTK_RO float4* light_filter;   // per light: w = 0: unit line direction g = L/|L| and rho = -1/|L|; w = 1: position minus DevScene::center
+  const RTK_RO uint32_t* light_kind;   // per light: 0 (w == 0), 1 (w == 1), 2 (anything else)
+  const RTK_RO float4* k_table;        // [batch][sphere][k_width]: c_j.g_k - R_j'^2 rho_k, only when lights_uniform
+  const RTK_RO float4* sph_tab;        // {cx, cy, cz, kappa |c|^2 - R'^2}: sphere record of the tabulated shadow filter
+  const RTK_RO float4* sph_ball;       // {cx, cy, cz, R'}: record of the wavefront-level test; padding has R' = -1e30
+  const RTK_RO float4* cluster_ball;   // one ball around each aligned run of kBundle spheres; padded to kBundle with R = -1e30
   uint32_t n_objects, n_lights, n_spheres, n_spheres_padded, n_planes;
   uint32_t n_clusters_padded;
   uint32_t n_spheres_grouped;  // n_spheres rounded up to kGroup: what the one-ray-per-lane sweeps cover

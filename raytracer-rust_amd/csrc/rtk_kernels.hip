@@ -101,7 +101,7 @@ __device__ __forceinline__ bool shadow_brute(const DevScene& S, bool active, V3 
   if (!active) return false;
   for (uint32_t k = 0; k < S.n_lights; ++k) {
     ++n_rays;
-    const DevLight& L = S.lights[k];
+    const RTK_RO DevLight& L = S.lights[k];
     const V3 lv = ld3(L.pos) - p;
     const double lw = L.pos[3] - 1.0;
     const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
@@ -173,7 +173,7 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
     V3 over = {0, 0, 0}, normal = {0, 0, 1}, eye = {0, 0, 1}, tex = {0, 0, 0};
     uint32_t obj = hit ? best.obj : 0u;
     if (hit) {
-      const DevObject& ob = S.objects[obj];
+      const RTK_RO DevObject& ob = S.objects[obj];
       HitGeom g = lighting_data(ob, ro, rd, best.t);
       over = g.over;
       normal = g.normal;
@@ -239,7 +239,7 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
     const bool in_shadow = BRUTE ? shadow_brute(S, hit, over, c_shadow) : shadow_sweeps<LB, WIDE>(S, hit, over, c_shadow, c_exact);
 
     if (hit) {
-      const DevObject& ob = S.objects[obj];
+      const RTK_RO DevObject& ob = S.objects[obj];
       V3 surface = scene_ambient;
       for (uint32_t k = 0; k < S.n_lights; ++k)
         surface = surface + phong_lighting(S.lights[k], ob, tex, over, eye, normal, in_shadow);

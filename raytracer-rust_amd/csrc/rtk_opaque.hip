@@ -57,6 +57,21 @@ __device__ __forceinline__ uint32_t launder(uint32_t v) {
 
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
+// Per-lane values parked in LDS between the phases of the fused kernel (the register file is full
+// at four wavefronts per SIMD; re-deriving a camera direction costs a square root and three
+// divisions, fetching it back three 8-byte LDS reads).  One array of 256 doubles per component,
+// so a wavefront's lanes read consecutive addresses.  A lane only ever reads what it wrote itself:
+// no barrier is involved.
+struct Stash {
+  double dir[3][kBlock];     // unit camera-ray direction
+  double over[3][kBlock];    // over_position of the hit
+  double normal[3][kBlock];  // its (flipped) normal
+};
+__device__ __forceinline__ void put3(double (*a)[kBlock], V3 v) {
+  a[0][threadIdx.x] = v.x, a[1][threadIdx.x] = v.y, a[2][threadIdx.x] = v.z;
+}
+__device__ __forceinline__ V3 get3(double (*a)[kBlock]) { return {a[0][threadIdx.x], a[1][threadIdx.x], a[2][threadIdx.x]}; }
+
 // Where a thread's pixel sits: local tile k (global tile k*world + rank), slot (lx, ly).
 struct PixelRef {
   uint32_t x, y;   // frame coordinates
@@ -114,13 +129,14 @@ __device__ __forceinline__ bool cone_reaches(const Cone& c, float4 ball) {
 __device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera& C, const float4* __restrict__ prim,
                                               const float4* __restrict__ prim_ball,
                                               const float4* __restrict__ prim_cluster, const PixelRef& px, Closest& best,
-                                              unsigned& n_exact) {
+                                              unsigned& n_exact, Stash* stash = nullptr) {
   const V3 origin = ld3(C.origin);
   const uint32_t lane = threadIdx.x & 63u;
   closest_init(best);
   float dx, dy, dz;
   {
     const V3 d = camera_ray_direction(C, px.x, px.y);
+    if (stash) put3(stash->dir, d);
     dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
     for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
       const uint32_t obj = S.plane_object[ip];
@@ -152,7 +168,7 @@ __device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera
           if (pass) {
             ++n_exact;
             double t0, t1;
-            const V3 d = camera_ray_direction(C, launder(px.x), px.y);
+            const V3 d = stash ? get3(stash->dir) : camera_ray_direction(C, launder(px.x), px.y);
             if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
               closest_consider(best, t0, obj, false);
               closest_consider(best, t1, obj, false);
@@ -192,7 +208,7 @@ __device__ __forceinline__ V3 over_point(const DevScene& S, const DevCamera& C, 
 
 // One shadow ray against one object, exactly: the per-light body of `Scene::is_shadowed`
 // (src/scene.rs:208-225).
-__device__ __forceinline__ bool shadow_ray_blocked(const DevObject& ob, const DevLight& L, V3 p) {
+__device__ __forceinline__ bool shadow_ray_blocked(const RTK_RO DevObject& ob, const RTK_RO DevLight& L, V3 p) {
   V3 lv = ld3(L.pos) - p;
   const double lw = L.pos[3] - 1.0;
   const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
@@ -305,7 +321,7 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
       live = !(occl & 1u);
       if (live) arm(f, S, p, kb, nb);
     }
-    const float4* __restrict__ ktab = S.k_table + (size_t)batch * S.n_spheres_padded * KV;
+    const RTK_RO float4* ktab = S.k_table + (size_t)batch * S.n_spheres_padded * KV;
 
     // bundle of the patch; the slack covers the FP32 rounding of points and centres
     const Ball ball = make_ball(live, f.x, f.y, f.z);
@@ -369,7 +385,7 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
           }
           mask &= ~occl;
           if (wave_any(mask != 0)) {
-            const DevObject& ob = S.objects[S.sph_object[j]];
+            const RTK_RO DevObject& ob = S.objects[S.sph_object[j]];
             if (mask) {
               for (uint32_t r = 0; r < nb; ++r)
                 if ((mask >> r) & 1u) {
@@ -547,7 +563,7 @@ __device__ __forceinline__ bool shadow_phase_bundled(const DevScene& S, bool nee
             if ((cones >> k) & 1u) {
               // direction from the f64 difference, normalised in FP32 (rsq: 1 ulp); the factor on h^2
               // below covers the direction's length being off by a few ulp
-              const DevLight& L = S.lights[kb + min((uint32_t)k, nb - 1u)];
+              const RTK_RO DevLight& L = S.lights[kb + min((uint32_t)k, nb - 1u)];
               const float gx = (float)(L.pos[0] - p.x), gy = (float)(L.pos[1] - p.y), gz = (float)(L.pos[2] - p.z);
               const float gg = __builtin_fmaf(gz, gz, __builtin_fmaf(gy, gy, gx * gx));
               h = __builtin_fmaf(uz, gz, __builtin_fmaf(uy, gy, ux * gx)) * __builtin_amdgcn_rsqf(gg);
@@ -560,7 +576,7 @@ __device__ __forceinline__ bool shadow_phase_bundled(const DevScene& S, bool nee
           if (!live) mask = 0;
           mask &= ~occl;
           if (wave_any(mask != 0)) {
-            const DevObject& ob = S.objects[S.sph_object[j]];
+            const RTK_RO DevObject& ob = S.objects[S.sph_object[j]];
             if (mask) {
               for (uint32_t r = 0; r < nb; ++r)
                 if ((mask >> r) & 1u) {
@@ -597,7 +613,7 @@ __device__ __forceinline__ bool shadow_phase_bundled(const DevScene& S, bool nee
 // refracted parts are BLACK, what is left is ambient + the Phong sum over the lights.
 __device__ __forceinline__ V3 shade_hit(const DevScene& S, const DevCamera& C, const PixelRef& px, uint32_t obj, double t,
                                         bool in_shadow) {
-  const DevObject& ob = S.objects[obj];
+  const RTK_RO DevObject& ob = S.objects[obj];
   const V3 d = camera_ray_direction(C, px.x, px.y);
   const HitGeom g = lighting_data(ob, ld3(C.origin), d, t);
   const V3 tex = sample_texture_at(S, ob, obj, g.objp);
@@ -630,7 +646,20 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, 
   if ((threadIdx.x & 63u) == 0) atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)n_shadow);
 }
 
-// All three steps in one kernel (every light has w = 0): no hit records cross HBM.
+// `apply_lighting` for the fused kernel: the hit geometry comes back from the stash
+// (LightingData::calculate ran once, in the shadow set-up) instead of being derived again.
+__device__ __forceinline__ V3 shade_hit_stashed(const DevScene& S, uint32_t obj, bool in_shadow, Stash* stash) {
+  const RTK_RO DevObject& ob = S.objects[obj];
+  const V3 over = get3(stash->over), normal = get3(stash->normal), eye = -get3(stash->dir);
+  const V3 objp = xform(ob.inv, over, 1.0);  // as LightingData computes it (src/scene/lighting.rs:52)
+  const V3 tex = sample_texture_at(S, ob, obj, objp);
+  V3 surface = ld3(S.ambient);
+  for (uint32_t l = 0; l < S.n_lights; ++l)
+    surface = surface + phong_lighting(S.lights[l], ob, tex, over, eye, normal, in_shadow);
+  return surface;
+}
+
+// All three steps in one kernel (every light has w = 0 or 1): no hit records cross HBM.
 template <int KW, bool TABULATED>
 __global__ void __launch_bounds__(kBlock, 4) render_uniform_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                                   const float4* __restrict__ prim_ball,
@@ -638,20 +667,26 @@ __global__ void __launch_bounds__(kBlock, 4) render_uniform_kernel(DevScene S, D
                                                                   DevCounters* counters) {
   __shared__ float s_rgb[768];
   __shared__ uint32_t s_px[256];
+  __shared__ Stash stash;
   const uint32_t k = T.n_local_tiles - 1u - blockIdx.x;
   const PixelRef px = pixel_ref(T, C, k);
   Closest best;
   unsigned n_exact = 0;
-  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, n_exact);
+  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, n_exact, &stash);
   const uint32_t obj = px.valid ? best.obj : 0xffffffffu;
   const bool hit = obj != 0xffffffffu;
   V3 p = {0, 0, 0};
-  if (hit) p = over_point(S, C, px, obj, best.t);
+  if (hit) {
+    const HitGeom g = lighting_data(S.objects[obj], ld3(C.origin), get3(stash.dir), best.t);
+    put3(stash.over, g.over);
+    put3(stash.normal, g.normal);
+    p = g.over;
+  }
   unsigned rays = 0;
   const bool in_shadow = TABULATED ? shadow_phase_uniform<KW>(S, hit, p, rays, n_exact)
                                    : shadow_phase_bundled<KW>(S, hit, p, rays, n_exact);
   V3 color = {0, 0, 0};
-  if (px.valid) color = hit ? shade_hit(S, C, px, launder(obj), best.t, in_shadow) : ld3(S.ambient);
+  if (px.valid) color = hit ? shade_hit_stashed(S, launder(obj), in_shadow, &stash) : ld3(S.ambient);
   store_tile(C, T, k, color, s_rgb, s_px);
   const unsigned n_primary = wave_sum(px.valid ? 1u : 0u);
   rays = wave_sum(rays);

@@ -31,10 +31,14 @@ __device__ __forceinline__ V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
 __device__ __forceinline__ V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 __device__ __forceinline__ double dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ V3 ld3(const double* p) { return {p[0], p[1], p[2]}; }
+template <typename P>
+__device__ __forceinline__ V3 ld3(P p) {  // P: pointer to doubles in any address space
+  return {p[0], p[1], p[2]};
+}
 
 // rows 0..2 of an affine 4x4 times (v, w): the 4-term rows of src/maths/vectors.rs:205-223
-__device__ __forceinline__ V3 xform(const double* m, V3 v, double w) {
+template <typename P>
+__device__ __forceinline__ V3 xform(P m, V3 v, double w) {
   return {m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * w, m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7] * w,
           m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * w};
 }
@@ -44,8 +48,8 @@ __device__ __forceinline__ V3 xform(const double* m, V3 v, double w) {
 // `Sphere::intersect` (src/scene/shapes/spheres.rs:18-35) or `Plane::intersect`
 // (src/scene/shapes/planes.rs:22-28).  The ray origin has w = 1; dw is the direction's w
 // (0 for camera and secondary rays, non-zero for shadow rays towards a w != 1 light).
-__device__ __forceinline__ int intersect_object(const DevObject& ob, V3 o, V3 d, double dw, double& t0, double& t1) {
-  const double* m = ob.inv;
+__device__ __forceinline__ int intersect_object(const RTK_RO DevObject& ob, V3 o, V3 d, double dw, double& t0, double& t1) {
+  const RTK_RO double* m = ob.inv;
   if (ob.kind == 1u) {
     double oy = m[4] * o.x + m[5] * o.y + m[6] * o.z + m[7];
     double dy = m[4] * d.x + m[5] * d.y + m[6] * d.z + m[7] * dw;
@@ -77,8 +81,8 @@ __device__ __forceinline__ int intersect_object(const DevObject& ob, V3 o, V3 d,
 // (|d'.y m - g| <= 6 ulp of the sum of the terms' magnitudes).  When o'.y and d'.y share a
 // sign, t < 0, and when o'.y == 0, t == 0: `is_shadowed` (src/scene.rs:208-225) wants
 // t > 0 either way, so the square root and the divisions can be skipped.  Returns false only then.
-__device__ __forceinline__ bool plane_may_block(const DevObject& ob, const DevLight& L, V3 p) {
-  const double* m = ob.inv;
+__device__ __forceinline__ bool plane_may_block(const RTK_RO DevObject& ob, const RTK_RO DevLight& L, V3 p) {
+  const RTK_RO double* m = ob.inv;
   const double oy = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
   const double a = m[4] * (L.pos[0] - p.x), b = m[5] * (L.pos[1] - p.y), c = m[6] * (L.pos[2] - p.z), d = m[7] * (L.pos[3] - 1.0);
   const double g = a + b + c + d;
@@ -154,7 +158,7 @@ __device__ __forceinline__ float filter_threshold(const DevScene& S, V3 pc, floa
 
 // `Texture::sample_at` (src/scene/materials.rs:14-19) and the four patterns
 // (src/graphics/patterns.rs:57-65, 81-88, 105-116, 132-140).  Rust's `%` is fmod.
-__device__ __forceinline__ V3 sample_texture(const DevObject& ob, V3 p) {
+__device__ __forceinline__ V3 sample_texture(const RTK_RO DevObject& ob, V3 p) {
   V3 a = ld3(ob.color_a), b = ld3(ob.color_b);
   switch (ob.texture_kind & 0xffu) {
     case 1u:  // checker
@@ -179,7 +183,7 @@ __device__ __forceinline__ V3 sample_texture(const DevObject& ob, V3 p) {
 // object-space point (w = 1) goes through the inverse pattern transform first.  The inverse
 // is formed once at scene upload with the reference's cofactor method; a singular transform
 // is stored as "no transform".
-__device__ __forceinline__ V3 sample_texture_at(const DevScene& S, const DevObject& ob, uint32_t obj, V3 objp) {
+__device__ __forceinline__ V3 sample_texture_at(const DevScene& S, const RTK_RO DevObject& ob, uint32_t obj, V3 objp) {
   if (ob.texture_kind & 0x80000000u) objp = xform(S.pattern_inv + 12 * (size_t)obj, objp, 1.0);
   return sample_texture(ob, objp);
 }
@@ -188,7 +192,7 @@ __device__ __forceinline__ V3 sample_texture_at(const DevScene& S, const DevObje
 struct HitGeom {
   V3 over, under, normal, eye, reflect, objp;
 };
-__device__ __forceinline__ HitGeom lighting_data(const DevObject& ob, V3 o, V3 d, double t) {
+__device__ __forceinline__ HitGeom lighting_data(const RTK_RO DevObject& ob, V3 o, V3 d, double t) {
   HitGeom h;
   V3 world = o + d * t;
   h.eye = -d;
@@ -198,7 +202,7 @@ __device__ __forceinline__ HitGeom lighting_data(const DevObject& ob, V3 o, V3 d
   } else {
     // src/scene/shapes/spheres.rs:37-44: inverse^T * (object_point - origin), w := 0, normalize
     V3 op = xform(ob.inv, world, 1.0);
-    const double* m = ob.inv;
+    const RTK_RO double* m = ob.inv;
     n = {m[0] * op.x + m[4] * op.y + m[8] * op.z, m[1] * op.x + m[5] * op.y + m[9] * op.z,
          m[2] * op.x + m[6] * op.y + m[10] * op.z};
     double mag = sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
@@ -217,7 +221,7 @@ __device__ __forceinline__ HitGeom lighting_data(const DevObject& ob, V3 o, V3 d
 // `phong_lighting` (src/scene/lighting.rs:120-154) for one light; `tex` is the sampled
 // texture colour.  The light vector is normalised over four components: its w is
 // L.w - 1 (the shading point has w = 1).
-__device__ __forceinline__ V3 phong_lighting(const DevLight& L, const DevObject& ob, V3 tex, V3 over, V3 eye, V3 normal,
+__device__ __forceinline__ V3 phong_lighting(const RTK_RO DevLight& L, const RTK_RO DevObject& ob, V3 tex, V3 over, V3 eye, V3 normal,
                                              bool in_shadow) {
   V3 intensity = ld3(L.intensity);
   V3 effective = tex * intensity;

@@ -239,9 +239,9 @@ __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3
     // planes: exact, per light (the shadow ray is rebuilt once per light)
     if (need) {
       for (uint32_t r = 0; r < nb; ++r) {
-        const DevLight& L = S.lights[kb + r];
+        const RTK_RO DevLight& L = S.lights[kb + r];
         for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
-          const DevObject& ob = S.objects[S.plane_object[ip]];
+          const RTK_RO DevObject& ob = S.objects[S.plane_object[ip]];
           if (!plane_may_block(ob, L, p)) continue;
           V3 lv = ld3(L.pos) - p;
           double lw = L.pos[3] - 1.0;
@@ -260,7 +260,7 @@ __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3
     bool exotic = false;
 #pragma unroll
     for (int r = 0; r < LB; ++r) {
-      const DevLight& L = S.lights[kb + min((uint32_t)r, nb - 1)];  // pad with the last real light
+      const RTK_RO DevLight& L = S.lights[kb + min((uint32_t)r, nb - 1)];  // pad with the last real light
       double lw = L.pos[3];
       V3 G = ld3(L.pos) - p * lw;
       make_filter_ray(G, lw - 1.0, gx[r], gy[r], gz[r], rho[r]);
@@ -271,10 +271,10 @@ __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3
     float thr = exotic ? -3.0e38f : filter_threshold(S, pc, rho_max);
     bool live = need && !(occl & 1u);
     auto exact = [&](uint32_t obj, uint32_t mask) {
-      const DevObject& ob = S.objects[obj];
+      const RTK_RO DevObject& ob = S.objects[obj];
       for (uint32_t r = 0; r < nb; ++r) {
         if (!((mask >> r) & 1u) || ((occl >> r) & 1u)) continue;
-        const DevLight& L = S.lights[kb + r];
+        const RTK_RO DevLight& L = S.lights[kb + r];
         V3 lv = ld3(L.pos) - p;
         double lw = L.pos[3] - 1.0;
         double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);

@@ -1,0 +1,69 @@
+"""One frame over several GPUs from ONE process: binding of the rtk_group_* entry points.
+
+Member r renders the bands of whole tile rows dealt to r; members other than the first send their
+bands with RCCL and the first (the root) receives each band straight into its final rows of the
+frame (csrc/rtk_group.hip).  Pixels are independent (src/scene/cameras.rs:75-82), so the frame is
+bit-identical to the single-GPU frame.  A device may be named more than once: such members exchange
+through RCCL's send-to-self, which runs every step of the multi-GPU frame on a one-GPU machine.
+"""
+import ctypes as C
+
+from . import abi
+from . import device as _device
+
+
+class DeviceGroup:
+    def __init__(self, device_ids):
+        import torch
+
+        self.torch = torch
+        ids = [int(d) for d in device_ids]
+        if not ids:
+            raise ValueError("a group needs at least one device")
+        self.device_ids = ids
+        self.tdev = torch.device("cuda", ids[0])  # the root: frames land here
+        self.side_stream = None                   # see device._OnStream
+        arr = (C.c_int * len(ids))(*ids)
+        g = C.c_void_p()
+        _device._check(_device.library().rtk_group_create(arr, len(ids), C.byref(g)))
+        self.group = g
+        self._scene = None
+
+    def close(self):
+        if self.group:
+            _device.library().rtk_group_destroy(self.group)
+            self.group = None
+
+    def __len__(self):
+        return int(_device.library().rtk_group_size(self.group))
+
+    def upload(self, scene):
+        s = scene.to_abi() if hasattr(scene, "to_abi") else scene
+        _device._check(_device.library().rtk_group_upload(self.group, C.byref(s)))
+        self._scene = s
+
+    def band_tile_rows(self, height):
+        return int(_device.library().rtk_group_band_tile_rows(self.group, height))
+
+    def render_device(self, camera, want_rgb=True, want_rgba8=True, out_rgb=None, out_rgba8=None):
+        """Queues one frame; returns ([H, W, 3] float32, [H, W, 4] uint8) tensors on the root's device.
+        Asynchronous on torch's current stream of that device."""
+        torch = self.torch
+        cam = camera.to_abi() if hasattr(camera, "to_abi") else camera
+        rgb = rgba = None
+        if want_rgb:
+            rgb = out_rgb if out_rgb is not None else torch.empty((cam.height, cam.width, 3), dtype=torch.float32, device=self.tdev)
+        if want_rgba8:
+            rgba = out_rgba8 if out_rgba8 is not None else torch.empty((cam.height, cam.width, 4), dtype=torch.uint8, device=self.tdev)
+        with _device._OnStream(self) as stream:
+            _device._check(_device.library().rtk_group_render_device(
+                self.group, C.byref(cam),
+                C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
+                C.c_void_p(rgba.data_ptr()) if rgba is not None else None,
+                stream))
+        return rgb, rgba
+
+    def stats(self):
+        st = abi.rtk_stats()
+        _device._check(_device.library().rtk_group_get_stats(self.group, C.byref(st)))
+        return st

@@ -2,6 +2,10 @@
 usage: python tools/pmc_summary.py gpurun_out/prof_<tag> [--json out.json]"""
 import collections, csv, glob, json, sys
 
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402
+
 src = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
@@ -58,7 +62,13 @@ for name, counters in sorted(agg.items()):
             f32_flops = (m.get("SQ_INSTS_VALU_ADD_F32", 0) + m.get("SQ_INSTS_VALU_MUL_F32", 0) + 2.0 * m.get("SQ_INSTS_VALU_FMA_F32", 0)) * lanes
             d["executed_f64_tflops"] = f64_flops / (d["avg_ms"] * 1e-3) / 1e12
             d["executed_f32_tflops"] = f32_flops / (d["avg_ms"] * 1e-3) / 1e12
+            d["f64_flops_per_launch"] = f64_flops
+            d["f32_flops_per_launch"] = f32_flops
         d["valu_busy_from_mix"] = (4.0 * f64 + 16.0 * t64 + 8.0 * t32 + 2.0 * rest) / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0)
+    if "SQ_WAIT_ANY" in m and m.get("SQ_WAVE_CYCLES"):
+        d["wait_any_share"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]   # wave cycles parked on a counter
+    if "SQ_WAIT_INST_ANY" in m and m.get("SQ_WAVE_CYCLES"):
+        d["issue_stall_share"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
     if "SQ_WAVES" in m and "SQ_INSTS_VALU" in m:
         d["valu_per_wave"] = m["SQ_INSTS_VALU"] / m["SQ_WAVES"]
     out[name] = d
@@ -91,8 +101,15 @@ if "--measured" in sys.argv:
         "valu_lane_util": d.get("valu_lane_util"),
         "executed_f64_tflops": d.get("executed_f64_tflops"),
         "executed_f32_tflops": d.get("executed_f32_tflops"),
+        "f64_flops_per_launch": d.get("f64_flops_per_launch"),
+        "f32_flops_per_launch": d.get("f32_flops_per_launch"),
+        "wait_any_share": d.get("wait_any_share"),
+        "issue_stall_share": d.get("issue_stall_share"),
+        "valu_per_wave": d.get("valu_per_wave"),
         "avg_waves_per_simd": d.get("avg_waves_per_simd"),
         "clock_GHz": d.get("clock_GHz"),
         "source": src,
+        # bench.py quotes these figures only for the tree they were taken from
+        "source_sha256": kernel_source_hash(),
     }
     json.dump(allw, open(path, "w"), indent=1)

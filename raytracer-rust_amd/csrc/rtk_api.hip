@@ -432,8 +432,8 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   bool any_pattern = false;
   for (uint32_t i = 0; i < scene->n_objects && !any_pattern; ++i) any_pattern = scene->objects[i].material.pattern_transformed != 0;
   const size_t n_all = scene->n_objects, n_padded = n_all + kBundle, n_l = scene->n_lights;
-  const size_t bound = 16 * 256 + n_all * sizeof(DevObject) + n_l * (sizeof(DevLight) + sizeof(float4) + sizeof(uint32_t)) +
-                       n_padded * (3 * sizeof(float4) + sizeof(uint32_t)) + n_all * (sizeof(double4) + sizeof(uint32_t)) +
+  const size_t bound = 17 * 256 + n_all * sizeof(DevObject) + n_l * (sizeof(DevLight) + sizeof(float4) + sizeof(uint32_t)) +
+                       n_padded * (3 * sizeof(float4) + sizeof(uint32_t) + sizeof(SphRecord)) + n_all * (sizeof(double4) + sizeof(uint32_t)) +
                        (any_pattern ? n_all * 12 * sizeof(double) : 0) + ((n_l + 3) / 4) * n_padded * sizeof(float4) +
                        (n_padded / kBundle + kBundle) * sizeof(float4);
   if (flat.grow) {
@@ -589,6 +589,19 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
     c_max = std::fmax(c_max, round_up(std::sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]) * 1.0001));
   }
 
+  // exact-test records in sweep order (padding repeats the last real one, like the filter records)
+  std::vector<SphRecord> sph_record(n_pad);
+  for (uint32_t j = 0; j < n_pad; ++j) {
+    const uint32_t obj = sph_object[j];
+    const double* m = objects[obj].inv;
+    SphRecord& r = sph_record[j];
+    r.scale[0] = m[0], r.scale[1] = m[5], r.scale[2] = m[10];
+    r.shift[0] = m[3], r.shift[1] = m[7], r.shift[2] = m[11];
+    r.object = obj;
+    r.diagonal = (m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[8] == 0.0 && m[9] == 0.0) ? 1u : 0u;
+    r.reserved_ = 0;
+  }
+
   // records of the wavefront-level test: centre and (not squared) inflated radius
   std::vector<float4> sph_ball(n_pad);
   for (uint32_t j = 0; j < n_pad; ++j) {
@@ -695,6 +708,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   place(&rtk_scene_handle::d_filter, filter.data(), filter.size() * sizeof(float4));
   place(&rtk_scene_handle::d_exact, sph_exact.data(), sph_exact.size() * sizeof(double4));
   place(&rtk_scene_handle::d_sph_object, sph_object.data(), sph_object.size() * sizeof(uint32_t));
+  place(&rtk_scene_handle::d_sph_record, sph_record.data(), sph_record.size() * sizeof(SphRecord));
   place(&rtk_scene_handle::d_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
   place(&rtk_scene_handle::d_pattern_inv, pattern_inv.data(), pattern_inv.size() * sizeof(double));
   place(&rtk_scene_handle::d_light_filter, light_filter.data(), light_filter.size() * sizeof(float4));
@@ -758,6 +772,7 @@ int rtk::place_scene(rtk_context* ctx, const rtk::FlatScene& flat, rtk_scene_han
   d.sph_filter = (decltype(d.sph_filter))h->d_filter;
   d.sph_exact = (decltype(d.sph_exact))h->d_exact;
   d.sph_object = (decltype(d.sph_object))h->d_sph_object;
+  d.sph_record = (decltype(d.sph_record))h->d_sph_record;
   d.plane_object = (decltype(d.plane_object))h->d_plane_object;
   d.pattern_inv = (decltype(d.pattern_inv))h->d_pattern_inv;
   d.light_filter = (decltype(d.light_filter))h->d_light_filter;

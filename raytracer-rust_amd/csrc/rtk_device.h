@@ -30,6 +30,22 @@ struct DevObject {
   uint32_t texture_kind;  // bit 31: the pattern has a transform of its own, see DevScene::pattern_inv
 };
 
+// What the exact test of one sphere needs, in sweep (cluster) order like the filter records, so
+// that a candidate's record is found from its position j without going through sph_object.
+// For a sphere whose inverse transform is a diagonal 3x3 plus a translation (every sphere placed by
+// translate * scale, whatever the three scale factors) the six numbers below ARE the inverse: the
+// other six entries of its rows are zeros, and leaving their products out of the reference's row
+// sums (src/maths/vectors.rs:205-223) changes no sum except, at most, the sign of a zero, which no
+// decision of the intersection depends on.  Other spheres keep the full rows in DevObject::inv.
+struct SphRecord {
+  double scale[3];    // inv[0], inv[5], inv[10]
+  double shift[3];    // inv[3], inv[7], inv[11]
+  uint32_t object;    // index into DevScene::objects
+  uint32_t diagonal;  // 1: scale/shift are the whole inverse; 0: use objects[object].inv
+  uint64_t reserved_;
+};
+static_assert(sizeof(SphRecord) == 64, "one sphere record is one 64-byte scalar load");
+
 struct DevLight {
   double pos[4];  // position incl. the reference's w (src/scene/lighting.rs:8-11)
   double intensity[3];
@@ -63,6 +79,7 @@ struct DevScene {
   const RTK_RO float4* sph_filter;
   const RTK_RO double4* sph_exact;     // centre (world, f64) and bounding radius per filter record
   const RTK_RO uint32_t* sph_object;   // filter record -> object index
+  const RTK_RO SphRecord* sph_record;  // filter record -> what its exact test needs (padded like the filter records)
   const RTK_RO uint32_t* plane_object; // plane list -> object index
   const RTK_RO double* pattern_inv;    // per object, rows 0..2 of the inverse pattern transform (12 f64); null when no pattern has one
   const RTK_RO float4* light_filter;   // per light: w = 0: unit line direction g = L/|L| and rho = -1/|L|; w = 1: position minus DevScene::center

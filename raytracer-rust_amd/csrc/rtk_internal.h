@@ -36,6 +36,7 @@ struct rtk_scene_handle {
   void* d_filter = nullptr;
   void* d_exact = nullptr;
   void* d_sph_object = nullptr;
+  void* d_sph_record = nullptr;
   void* d_plane_object = nullptr;
   void* d_light_kind = nullptr;
   void* d_pattern_inv = nullptr;

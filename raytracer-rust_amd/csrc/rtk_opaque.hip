@@ -164,14 +164,14 @@ __device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera
         t = __builtin_fmaf(r.z, dz, t);
         const bool pass = px.valid && __builtin_fmaf(t, t, -r.w) >= 0.0f;
         if (wave_any(pass)) {
-          const uint32_t obj = S.sph_object[j];
+          const RTK_RO SphRecord& rec = S.sph_record[j];
           if (pass) {
             ++n_exact;
             double t0, t1;
             const V3 d = stash ? get3(stash->dir) : camera_ray_direction(C, launder(px.x), px.y);
-            if (intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) {
-              closest_consider(best, t0, obj, false);
-              closest_consider(best, t1, obj, false);
+            if (intersect_sphere_record(S, rec, origin, d, 0.0, t0, t1)) {
+              closest_consider(best, t0, rec.object, false);
+              closest_consider(best, t1, rec.object, false);
             }
           }
         }
@@ -216,6 +216,17 @@ __device__ __forceinline__ bool shadow_ray_blocked(const RTK_RO DevObject& ob, c
   double t0, t1;
   const int n = intersect_object(ob, p, d, lw / m, t0, t1);
   return (n >= 1 && t0 > 0.0 && t0 < m) || (n == 2 && t1 > 0.0 && t1 < m);
+}
+
+// The same against a sphere given by its sweep-order record.
+__device__ __forceinline__ bool shadow_ray_blocked(const DevScene& S, const RTK_RO SphRecord& rec, const RTK_RO DevLight& L, V3 p) {
+  V3 lv = ld3(L.pos) - p;
+  const double lw = L.pos[3] - 1.0;
+  const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+  const V3 d = {lv.x / m, lv.y / m, lv.z / m};
+  double t0, t1;
+  const int n = intersect_sphere_record(S, rec, p, d, lw / m, t0, t1);
+  return n == 2 && ((t0 > 0.0 && t0 < m) || (t1 > 0.0 && t1 < m));
 }
 
 // The tabulated filter of one pixel.  With the recentred, FP32-rounded shading point p,
@@ -385,12 +396,12 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
           }
           mask &= ~occl;
           if (wave_any(mask != 0)) {
-            const RTK_RO DevObject& ob = S.objects[S.sph_object[j]];
+            const RTK_RO SphRecord& rec = S.sph_record[j];
             if (mask) {
               for (uint32_t r = 0; r < nb; ++r)
                 if ((mask >> r) & 1u) {
                   ++n_exact;
-                  if (shadow_ray_blocked(ob, S.lights[kb + r], p)) occl |= 1u << r;
+                  if (shadow_ray_blocked(S, rec, S.lights[kb + r], p)) occl |= 1u << r;
                 }
             }
             changed = true;
@@ -576,12 +587,12 @@ __device__ __forceinline__ bool shadow_phase_bundled(const DevScene& S, bool nee
           if (!live) mask = 0;
           mask &= ~occl;
           if (wave_any(mask != 0)) {
-            const RTK_RO DevObject& ob = S.objects[S.sph_object[j]];
+            const RTK_RO SphRecord& rec = S.sph_record[j];
             if (mask) {
               for (uint32_t r = 0; r < nb; ++r)
                 if ((mask >> r) & 1u) {
                   ++n_exact;
-                  if (shadow_ray_blocked(ob, S.lights[kb + r], p)) occl |= 1u << r;
+                  if (shadow_ray_blocked(S, rec, S.lights[kb + r], p)) occl |= 1u << r;
                 }
             }
             changed = true;
@@ -660,8 +671,11 @@ __device__ __forceinline__ V3 shade_hit_stashed(const DevScene& S, uint32_t obj,
 }
 
 // All three steps in one kernel (every light has w = 0 or 1): no hit records cross HBM.
+// Five wavefronts per SIMD (96 VGPRs): with the object records in scalar registers the kernel
+// spills 88 bytes per lane there and still runs faster than at four wavefronts without spills
+// (C4 0.83 against 0.86 ms, a 4096^2 C5 1.39 against 1.48); six wavefronts lose again.
 template <int KW, bool TABULATED>
-__global__ void __launch_bounds__(kBlock, 4) render_uniform_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
+__global__ void __launch_bounds__(kBlock, 5) render_uniform_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                                   const float4* __restrict__ prim_ball,
                                                                   const float4* __restrict__ prim_cluster, RenderTarget T,
                                                                   DevCounters* counters) {

@@ -43,6 +43,23 @@ __device__ __forceinline__ V3 xform(P m, V3 v, double w) {
           m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * w};
 }
 
+// `Sphere::intersect` (src/scene/shapes/spheres.rs:18-35) on an object-space ray: the unit-sphere
+// quadratic.  direction.w stays dw (row 3 of the transforms is 0 0 0 1) and takes part in `a`;
+// sphere_to_ray.w = 1 - 1 = 0.
+__device__ __forceinline__ int unit_sphere_roots(V3 oo, V3 dd, double dw, double& t0, double& t1) {
+  double a = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z + dw * dw;
+  double b = 2.0 * (oo.x * dd.x + oo.y * dd.y + oo.z * dd.z);
+  double c = (oo.x * oo.x + oo.y * oo.y + oo.z * oo.z) - 1.0;
+  double disc = b * b - 4.0 * a * c;
+  if (disc >= 0.0) {
+    double s = sqrt(disc);
+    t0 = (-b - s) / (2.0 * a);
+    t1 = (-b + s) / (2.0 * a);
+    return 2;
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------
 // Exact f64 intersection of one object: `SceneNode::intersect` (src/scene.rs:75-84) with
 // `Sphere::intersect` (src/scene/shapes/spheres.rs:18-35) or `Plane::intersect`
@@ -59,18 +76,17 @@ __device__ __forceinline__ int intersect_object(const RTK_RO DevObject& ob, V3 o
   }
   V3 oo = xform(m, o, 1.0);
   V3 dd = xform(m, d, dw);
-  // direction.w stays dw (row 3 = 0 0 0 1) and takes part in `a`; sphere_to_ray.w = 1 - 1 = 0
-  double a = dd.x * dd.x + dd.y * dd.y + dd.z * dd.z + dw * dw;
-  double b = 2.0 * (oo.x * dd.x + oo.y * dd.y + oo.z * dd.z);
-  double c = (oo.x * oo.x + oo.y * oo.y + oo.z * oo.z) - 1.0;
-  double disc = b * b - 4.0 * a * c;
-  if (disc >= 0.0) {
-    double s = sqrt(disc);
-    t0 = (-b - s) / (2.0 * a);
-    t1 = (-b + s) / (2.0 * a);
-    return 2;
-  }
-  return 0;
+  return unit_sphere_roots(oo, dd, dw, t0, t1);
+}
+
+// The same for a sphere given by its sweep-order record.  Diagonal inverse: the row sums of
+// inverse * origin and inverse * direction with their exact-zero terms left out.
+__device__ __forceinline__ int intersect_sphere_record(const DevScene& S, const RTK_RO SphRecord& r, V3 o, V3 d, double dw,
+                                                       double& t0, double& t1) {
+  if (r.diagonal == 0u) return intersect_object(S.objects[r.object], o, d, dw, t0, t1);
+  const V3 oo = {r.scale[0] * o.x + r.shift[0], r.scale[1] * o.y + r.shift[1], r.scale[2] * o.z + r.shift[2]};
+  const V3 dd = {r.scale[0] * d.x + r.shift[0] * dw, r.scale[1] * d.y + r.shift[1] * dw, r.scale[2] * d.z + r.shift[2] * dw};
+  return unit_sphere_roots(oo, dd, dw, t0, t1);
 }
 
 // Can the reference's shadow ray from p towards light L meet the plane `ob` at a positive

@@ -54,7 +54,7 @@ using rtk::fail_hip;
 //   shadow        RTK_STATIC_MAX_RECORD_PIXELS x u8
 namespace {
 constexpr size_t kStaticCounters = 0;
-constexpr size_t kStaticPrim = kStaticCounters + sizeof(rtk::DevCounters) * rtk::kCounterShards;
+constexpr size_t kStaticPrim = (kStaticCounters + sizeof(rtk::DevCounters) * rtk::kCounterSlots + 255u) & ~(size_t)255u;
 constexpr size_t kStaticPrimBall = kStaticPrim + (size_t)RTK_STATIC_MAX_SPHERES * sizeof(float4);
 constexpr size_t kStaticPrimCluster = kStaticPrimBall + (size_t)RTK_STATIC_MAX_SPHERES * sizeof(float4);
 constexpr size_t kStaticHitT = kStaticPrimCluster + (size_t)RTK_STATIC_MAX_SPHERES / rtk::kBundle * sizeof(float4);
@@ -292,8 +292,8 @@ int rtk_create(int device_id, rtk_context** out) {
       (e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = create_timing_events(ctx)) != hipSuccess ||
       (e = static_scratch_for_current_device(device_id, &ctx->static_scratch)) != hipSuccess ||
-      (e = hipMalloc((void**)&ctx->d_counters, sizeof(rtk::DevCounters) * rtk::kCounterShards)) != hipSuccess ||
-      (e = hipMemset(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards)) != hipSuccess) {
+      (e = hipMalloc((void**)&ctx->d_counters, sizeof(rtk::DevCounters) * rtk::kCounterSlots)) != hipSuccess ||
+      (e = hipMemset(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterSlots)) != hipSuccess) {
     rtk_destroy(ctx);
     return fail_hip(e, "rtk_create");
   }
@@ -927,7 +927,7 @@ static int frame_begin(Frame& f, rtk_context* ctx, rtk_scene_handle* scene, cons
   f.opaque = !scene->dev.any_secondary;
   if (ctx->n_timed && ctx->last_stream != f.st)
     RTK_HIP(hipStreamWaitEvent(f.st, ctx->ev_stop[(ctx->n_timed - 1) % RTK_TIMING_HISTORY], 0));
-  RTK_HIP(hipMemsetAsync(f.scr.counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, f.st));
+  RTK_HIP(hipMemsetAsync(f.scr.counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterSlots, f.st));
   RTK_HIP(rtk::launch_prep_primary(f.st, scene->dev, f.cam, f.scr.prim, f.scr.prim_ball, f.scr.prim_cluster));
   f.slot = (int)(ctx->n_timed % RTK_TIMING_HISTORY);
   RTK_HIP(hipEventRecord(ctx->ev_start[f.slot], f.st));  // the per-camera record kernel (microseconds) stays outside
@@ -956,7 +956,7 @@ static int frame_launch(Frame& f, const rtk::Partition& p, float* d_rgb_f32, uin
     RTK_HIP(rtk::launch_render_opaque(f.st, f.scene->dev, f.cam, f.scr.prim, f.scr.prim_ball, f.scr.prim_cluster, t,
                                       f.scr.opaque, f.scr.counters, split ? ctx->ev_rays[f.slot] : nullptr));
   } else {
-    RTK_HIP(rtk::launch_render(f.st, f.scene->dev, f.cam, f.scr.prim, f.scr.prim_cluster, t, f.scr.counters));
+    RTK_HIP(rtk::launch_render(f.st, f.scene->dev, f.cam, t, f.scr.counters));
   }
   return RTK_OK;
 }
@@ -1388,7 +1388,7 @@ int rtk_trace_rays(rtk_context* ctx, rtk_scene_handle* scene, const double* orig
     e = hipStreamWaitEvent(st, ctx->ev_stop[(ctx->n_timed - 1) % RTK_TIMING_HISTORY], 0);
   if (e == hipSuccess) e = hipMemcpyAsync(d_o, origins, n * 4 * sizeof(double), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_d, directions, n * 4 * sizeof(double), hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterShards, st);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterSlots, st);
   const int slot = (int)(ctx->n_timed % RTK_TIMING_HISTORY);
   ctx->ev_split[slot] = false;
   if (e == hipSuccess) e = hipEventRecord(ctx->ev_start[slot], st);

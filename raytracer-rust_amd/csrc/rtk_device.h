@@ -116,6 +116,9 @@ struct DevCamera {
 // the host sums the shards) -- a short kernel of 10^5 wavefronts would otherwise spend its
 // whole run time queueing on one word.
 constexpr int kCounterShards = 256;
+// Counter buffers hold one element more: the work counter of launches with persistent wavefronts.
+constexpr int kCounterSlots = kCounterShards + 1;
+constexpr uint32_t kPersistentGroups = 2048;  // workgroups of such a launch at most (256 CUs x 4 resident x 2)
 struct DevCounters {
   unsigned long long rays_primary, rays_shadow, rays_secondary, exact_tests;
 };

@@ -15,8 +15,9 @@ hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamer
                                float4* prim_cluster);
 
 // Renders the tiles selected by T.
-hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
-                         const float4* prim_cluster, const RenderTarget& T, DevCounters* counters);
+// `counters` holds kCounterShards shards followed by one more element whose first word is the
+// launch's work counter; all of it zeroed before the launch.
+hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const RenderTarget& T, DevCounters* counters);
 
 // Same for scenes without reflective or transparent materials: ray kernel(s) (camera +
 // shadow rays) and a shading kernel, with intermediate records in B.  `after_rays`, when not

@@ -26,6 +26,8 @@
 #include "rtk_sweeps.h"
 #include "rtk_kernels.h"
 
+#include <algorithm>
+
 #pragma clang fp contract(off)
 
 namespace rtk {
@@ -116,14 +118,120 @@ __device__ __forceinline__ bool shadow_brute(const DevScene& S, bool active, V3 
   return false;
 }
 
+// One node of the ray tree: `trace_inner` (src/scene.rs:141-153) for the ray (ro, rd) that enters the
+// pixel's colour with factor `weight`: closest hit, `apply_lighting` (src/scene.rs:172-205) with its
+// shadow rays, and the node's children pushed on the lane's stack.  camera_sweep: the ray is a camera
+// ray and the per-camera records may be used for its sweep.
+template <bool SECONDARY, bool PRIMARY_FILTER, int LB, bool WIDE, bool BRUTE, bool TRACK>
+__device__ __forceinline__ void trace_step(const DevScene& S, const float4* __restrict__ prim,
+                                           const float4* __restrict__ prim_cluster, bool have, bool camera_sweep, V3 ro, V3 rd,
+                                           double weight, int depth, StackEntry* stack, int& sp, V3& color, unsigned& c_primary,
+                                           unsigned& c_shadow, unsigned& c_secondary, unsigned& c_exact) {
+  const V3 scene_ambient = ld3(S.ambient);
+  if (have) {
+    if (depth == 0)
+      ++c_primary;
+    else
+      ++c_secondary;
+  }
+  Closest best;
+  bool graze = false;  // some sphere has both roots within 1e-5 of each other on this ray
+  if (BRUTE)
+    closest_brute<TRACK>(S, have, ro, rd, best, graze);
+  else if (PRIMARY_FILTER && camera_sweep)
+    closest_primary<TRACK>(S, prim, prim_cluster, have, ro, rd, best, c_exact, graze);
+  else
+    closest_general<WIDE, TRACK>(S, have, ro, rd, best, c_exact, graze);
+
+  const bool hit = have && best.obj != 0xffffffffu;
+  if (have && !hit) color = color + scene_ambient * weight;  // trace_inner: miss -> ambient_color
+
+  // --- apply_lighting (src/scene.rs:172-205) ---
+  V3 over = {0, 0, 0}, normal = {0, 0, 1}, eye = {0, 0, 1}, tex = {0, 0, 0};
+  uint32_t obj = hit ? best.obj : 0u;
+  if (hit) {
+    const RTK_RO DevObject& ob = S.objects[obj];
+    HitGeom g = lighting_data(ob, ro, rd, best.t);
+    over = g.over;
+    normal = g.normal;
+    eye = g.eye;
+    tex = sample_texture_at(S, ob, obj, g.objp);
+    if (SECONDARY) {
+      // children first, so that nothing of them stays live across the shadow sweep
+      const double reflectivity = ob.reflectivity, transparency = ob.transparency;
+      const bool has_refl = !is_approx_zero(reflectivity);   // reflected_color early-out
+      const bool has_refr = !is_approx_zero(transparency);   // refracted_color early-out
+      if (has_refl || has_refr) {
+        double n2 = ob.refractivity;
+        // n1: material of the entry just before the hit in the sorted list, else 1.0.  When
+        // every refractivity in the scene is 1.0 (track_n1 == 0) that is 1.0 either way.
+        // Two roots that close make the reference's container list drop entries: then by the letter.
+        double n1 = 1.0;
+        if constexpr (TRACK) {
+          if (graze)
+            n1 = literal_n1(S, ro, rd, obj, best.t);
+          else if (best.prev_obj != 0xffffffffu)
+            n1 = S.objects[best.prev_obj].refractivity;
+        }
+        const double cos_i = dot3(eye, normal);
+        double w_refl = weight * reflectivity, w_refr = weight * transparency;
+        if (reflectivity > 0.0 && transparency > 0.0) {
+          double reflectance = shlick(n1, n2, cos_i);
+          w_refl = weight * (reflectivity * reflectance);
+          w_refr = weight * (transparency * (1.0 - reflectance));
+        }
+        const bool child_traces = (uint32_t)(depth + 1) < S.max_depth;
+        if (has_refr) {  // src/scene.rs:244-272
+          double n_ratio = n1 / n2;
+          double sin_t2 = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
+          if (!(sin_t2 > 1.0)) {
+            double cos_t = sqrt(1.0 - sin_t2);
+            V3 dir = normal * (n_ratio + cos_i - cos_t) - eye * n_ratio;  // the reference's `+`
+            if (child_traces) {
+              StackEntry& e = stack[sp++];
+              e.ox = g.under.x, e.oy = g.under.y, e.oz = g.under.z;
+              e.dx = dir.x, e.dy = dir.y, e.dz = dir.z;
+              e.weight = w_refr;
+              e.depth = depth + 1;
+            } else {
+              color = color + scene_ambient * w_refr;  // trace_inner(depth >= MAX_DEPTH)
+            }
+          }
+        }
+        if (has_refl) {  // src/scene.rs:228-241
+          if (child_traces) {
+            StackEntry& e = stack[sp++];
+            e.ox = g.over.x, e.oy = g.over.y, e.oz = g.over.z;
+            e.dx = g.reflect.x, e.dy = g.reflect.y, e.dz = g.reflect.z;
+            e.weight = w_refl;
+            e.depth = depth + 1;
+          } else {
+            color = color + scene_ambient * w_refl;
+          }
+        }
+      }
+    }
+  }
+
+  const bool in_shadow = BRUTE ? shadow_brute(S, hit, over, c_shadow) : shadow_sweeps<LB, WIDE>(S, hit, over, c_shadow, c_exact);
+
+  if (hit) {
+    const RTK_RO DevObject& ob = S.objects[obj];
+    V3 surface = scene_ambient;
+    for (uint32_t k = 0; k < S.n_lights; ++k)
+      surface = surface + phong_lighting(S.lights[k], ob, tex, over, eye, normal, in_shadow);
+    color = color + surface * weight;
+  }
+}
+
+// `Scene::trace` (src/scene.rs:136-138) for one ray per lane: the tree is walked with a stack per lane,
+// every lane of the wavefront taking one node per round until all stacks are empty.
 template <bool SECONDARY, bool PRIMARY_FILTER, int LB, bool WIDE, bool BRUTE, bool TRACK>
 __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restrict__ prim,
                                         const float4* __restrict__ prim_cluster, bool valid, V3 o,
                                         V3 d, unsigned& c_primary, unsigned& c_shadow, unsigned& c_secondary,
                                         unsigned& c_exact) {
   V3 color = {0, 0, 0};
-  const V3 scene_ambient = ld3(S.ambient);
-
   StackEntry stack[SECONDARY ? kMaxDepth + 1 : 1];
   int sp = 0;
   // current ray
@@ -131,7 +239,7 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
   double weight = 1.0;
   int depth = 0;
   bool have = valid && S.max_depth > 0;
-  if (valid && S.max_depth == 0) color = scene_ambient;  // trace_inner(depth 0 >= MAX_DEPTH)
+  if (valid && S.max_depth == 0) color = ld3(S.ambient);  // trace_inner(depth 0 >= MAX_DEPTH)
 
   for (int iter = 0;; ++iter) {
     if (SECONDARY) {
@@ -150,116 +258,66 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
     } else if (iter > 0) {
       break;
     }
-
-    if (have) {
-      if (depth == 0)
-        ++c_primary;
-      else
-        ++c_secondary;
-    }
-    Closest best;
-    bool graze = false;  // some sphere has both roots within 1e-5 of each other on this ray
-    if (BRUTE)
-      closest_brute<TRACK>(S, have, ro, rd, best, graze);
-    else if (PRIMARY_FILTER && (!SECONDARY || iter == 0))
-      closest_primary<TRACK>(S, prim, prim_cluster, have, ro, rd, best, c_exact, graze);
-    else
-      closest_general<WIDE, TRACK>(S, have, ro, rd, best, c_exact, graze);
-
-    const bool hit = have && best.obj != 0xffffffffu;
-    if (have && !hit) color = color + scene_ambient * weight;  // trace_inner: miss -> ambient_color
-
-    // --- apply_lighting (src/scene.rs:172-205) ---
-    V3 over = {0, 0, 0}, normal = {0, 0, 1}, eye = {0, 0, 1}, tex = {0, 0, 0};
-    uint32_t obj = hit ? best.obj : 0u;
-    if (hit) {
-      const RTK_RO DevObject& ob = S.objects[obj];
-      HitGeom g = lighting_data(ob, ro, rd, best.t);
-      over = g.over;
-      normal = g.normal;
-      eye = g.eye;
-      tex = sample_texture_at(S, ob, obj, g.objp);
-      if (SECONDARY) {
-        // children first, so that nothing of them stays live across the shadow sweep
-        const double reflectivity = ob.reflectivity, transparency = ob.transparency;
-        const bool has_refl = !is_approx_zero(reflectivity);   // reflected_color early-out
-        const bool has_refr = !is_approx_zero(transparency);   // refracted_color early-out
-        if (has_refl || has_refr) {
-          double n2 = ob.refractivity;
-          // n1: material of the entry just before the hit in the sorted list, else 1.0.  When
-          // every refractivity in the scene is 1.0 (track_n1 == 0) that is 1.0 either way.
-          // Two roots that close make the reference's container list drop entries: then by the letter.
-          double n1 = 1.0;
-          if constexpr (TRACK) {
-            if (graze)
-              n1 = literal_n1(S, ro, rd, obj, best.t);
-            else if (best.prev_obj != 0xffffffffu)
-              n1 = S.objects[best.prev_obj].refractivity;
-          }
-          const double cos_i = dot3(eye, normal);
-          double w_refl = weight * reflectivity, w_refr = weight * transparency;
-          if (reflectivity > 0.0 && transparency > 0.0) {
-            double reflectance = shlick(n1, n2, cos_i);
-            w_refl = weight * (reflectivity * reflectance);
-            w_refr = weight * (transparency * (1.0 - reflectance));
-          }
-          const bool child_traces = (uint32_t)(depth + 1) < S.max_depth;
-          if (has_refr) {  // src/scene.rs:244-272
-            double n_ratio = n1 / n2;
-            double sin_t2 = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
-            if (!(sin_t2 > 1.0)) {
-              double cos_t = sqrt(1.0 - sin_t2);
-              V3 dir = normal * (n_ratio + cos_i - cos_t) - eye * n_ratio;  // the reference's `+`
-              if (child_traces) {
-                StackEntry& e = stack[sp++];
-                e.ox = g.under.x, e.oy = g.under.y, e.oz = g.under.z;
-                e.dx = dir.x, e.dy = dir.y, e.dz = dir.z;
-                e.weight = w_refr;
-                e.depth = depth + 1;
-              } else {
-                color = color + scene_ambient * w_refr;  // trace_inner(depth >= MAX_DEPTH)
-              }
-            }
-          }
-          if (has_refl) {  // src/scene.rs:228-241
-            if (child_traces) {
-              StackEntry& e = stack[sp++];
-              e.ox = g.over.x, e.oy = g.over.y, e.oz = g.over.z;
-              e.dx = g.reflect.x, e.dy = g.reflect.y, e.dz = g.reflect.z;
-              e.weight = w_refl;
-              e.depth = depth + 1;
-            } else {
-              color = color + scene_ambient * w_refl;
-            }
-          }
-        }
-      }
-    }
-
-    const bool in_shadow = BRUTE ? shadow_brute(S, hit, over, c_shadow) : shadow_sweeps<LB, WIDE>(S, hit, over, c_shadow, c_exact);
-
-    if (hit) {
-      const RTK_RO DevObject& ob = S.objects[obj];
-      V3 surface = scene_ambient;
-      for (uint32_t k = 0; k < S.n_lights; ++k)
-        surface = surface + phong_lighting(S.lights[k], ob, tex, over, eye, normal, in_shadow);
-      color = color + surface * weight;
-    }
+    trace_step<SECONDARY, PRIMARY_FILTER, LB, WIDE, BRUTE, TRACK>(S, prim, prim_cluster, have, iter == 0, ro, rd, weight, depth, stack,
+                                                                  sp, color, c_primary, c_shadow, c_secondary, c_exact);
   }
   return color;
 }
 
 // ------------------------------------------------------------------------------------
-// `Camera::render` (src/scene/cameras.rs:72-85): ray generation (cameras.rs:52-69 with the
-// matrix inverse hoisted to the host), trace, and the framebuffer store
-// (src/graphics.rs:44-46, 59-74).
-template <bool SECONDARY, int LB, bool WIDE, bool BRUTE, bool TRACK>
-__global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
-                                                        const float4* __restrict__ prim_cluster, RenderTarget T,
-                                                        DevCounters* counters) {
+// `Camera::render` (src/scene/cameras.rs:72-85) for scenes with reflective or transparent
+// materials: ray generation (cameras.rs:52-69 with the matrix inverse hoisted to the host), the
+// ray tree of every pixel, and the framebuffer store (src/graphics.rs:44-46, 59-74).
+//
+// Ray trees differ wildly from pixel to pixel (1 to 62 rays with the reference's depth of 5), so a
+// wavefront that walked the trees of 64 fixed pixels in lockstep would idle most lanes most of the
+// time.  Here the lanes are persistent: a lane whose pixel is finished stores it and takes the next
+// pixel of the wavefront's current 8x8 patch; when a patch is used up the wavefront draws the next
+// one from a counter shared by the whole launch.  A pixel is traced from its camera ray to its last
+// leaf by ONE lane, in the same order of operations whichever lane that is, so the frame does not
+// depend on how the pixels were dealt.  Patches are numbered from the bottom of the frame (the
+// expensive tiles) upwards.
+struct PixelSlot {
+  uint32_t x, y;      // frame coordinates
+  uint32_t k, lrow;   // local tile, local tile row (band layouts)
+  uint32_t lx, ly;    // position inside the tile
+};
+__device__ __forceinline__ PixelSlot pixel_slot(const RenderTarget& T, uint32_t patch, uint32_t slot) {
+  PixelSlot p;
+  p.k = T.n_local_tiles - 1u - (patch >> 2);
+  const TileRef tr = tile_ref(T, p.k);
+  p.lrow = tr.lrow;
+  p.lx = ((patch & 3u) << 3) | (slot & 7u);
+  p.ly = slot >> 3;
+  p.x = tr.tx * 32u + p.lx;
+  p.y = tr.ty * 8u + p.ly;
+  return p;
+}
+// One pixel to the outputs (row-major frame, the rank's tile-major buffer, or its own tile rows):
+// the narrowing to FP32 and the 8-bit cast of src/graphics.rs:59-74.
+__device__ __forceinline__ void store_pixel(const DevCamera& C, const RenderTarget& T, const PixelSlot& p, V3 color) {
+  size_t at;
+  if (T.layout == 1u)
+    at = (size_t)p.k * 256u + p.ly * 32u + p.lx;
+  else
+    at = (size_t)p.x + (size_t)(T.layout == 2u ? p.lrow * 8u + p.ly : p.y) * C.width;
+  if (T.rgb) {
+    T.rgb[at * 3u + 0u] = (float)color.x;
+    T.rgb[at * 3u + 1u] = (float)color.y;
+    T.rgb[at * 3u + 2u] = (float)color.z;
+  }
+  if (T.rgba8)
+    reinterpret_cast<uint32_t*>(T.rgba8)[at] = cast_u8(color.x) | (cast_u8(color.y) << 8) | (cast_u8(color.z) << 16) | 0xff000000u;
+}
+
+// Scenes of a handful of objects (the reference's bundled scene): a node costs little more than its
+// shading, and lanes that walk the trees of neighbouring pixels in lockstep take the same branches
+// of it, which is worth more there than keeping every lane busy (bundled scene at 1080p: 0.52 ms
+// against 0.74 ms with persistent lanes).  One lane per pixel of a 32x8 tile, as in the opaque path.
+template <bool TRACK>
+__global__ void __launch_bounds__(kBlock, 4) render_small_kernel(DevScene S, DevCamera C, RenderTarget T, DevCounters* counters) {
   __shared__ float s_rgb[768];  // store transpose only
   __shared__ uint32_t s_px[256];
-
   // expensive tiles (ground, bottom of the frame) first, cheap sky tiles last
   const uint32_t k = T.n_local_tiles - 1u - blockIdx.x;
   const TileRef tr = tile_ref(T, k);
@@ -267,14 +325,102 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera
   const uint32_t lx = (wave << 3) | (lane & 7u), ly = lane >> 3;
   const uint32_t x = tr.tx * 32u + lx, y = tr.ty * 8u + ly;
   const bool valid = x < C.width && y < C.height;
-
   const V3 origin = ld3(C.origin);
   const V3 dir = camera_ray_direction(C, x, y);  // cameras.rs:52-69
-
   unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
-  V3 color = trace_ray<SECONDARY, true, LB, WIDE, BRUTE, TRACK>(S, prim, prim_cluster, valid, origin, dir, c_primary, c_shadow, c_secondary, c_exact);
-
+  V3 color = trace_ray<true, false, 1, false, true, TRACK>(S, nullptr, nullptr, valid, origin, dir, c_primary, c_shadow, c_secondary, c_exact);
   store_tile(C, T, k, color, s_rgb, s_px);
+  c_primary = wave_sum(c_primary);
+  c_shadow = wave_sum(c_shadow);
+  c_secondary = wave_sum(c_secondary);
+  if (lane == 0) {
+    atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)c_primary);
+    atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)c_shadow);
+    atomicAdd(&counter_shard(counters)->rays_secondary, (unsigned long long)c_secondary);
+  }
+}
+
+template <int LB, bool WIDE, bool TRACK>
+__global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera C, RenderTarget T, DevCounters* counters,
+                                                        unsigned int* work) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t n_patches = T.n_local_tiles * 4u;
+  const V3 origin = ld3(C.origin);
+
+  StackEntry stack[kMaxDepth + 1];
+  int sp = 0;
+  V3 color = {0, 0, 0};
+  bool busy = false;                      // this lane holds a pixel
+  uint32_t my_patch = 0, my_slot = 0;     // ... this one
+  uint32_t cur_patch = 0, cur_next = 64;  // the wavefront's current patch and its next unassigned pixel
+  bool exhausted = false;                 // the launch has no patches left
+  unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
+
+  for (;;) {
+    // pixels for the idle lanes
+    while (!exhausted) {
+      const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
+      if (idle == 0ull) break;
+      if (cur_next >= 64u) {
+        unsigned int p = 0;
+        if (lane == 0) p = atomicAdd(work, 1u);
+        p = (unsigned int)__builtin_amdgcn_readfirstlane((int)p);
+        if (p >= n_patches) {
+          exhausted = true;
+          break;
+        }
+        cur_patch = p;
+        cur_next = 0;
+      }
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+      const uint32_t take = min((uint32_t)__builtin_popcountll(idle), 64u - cur_next);
+      if (!busy && rank < take) {
+        const PixelSlot p = pixel_slot(T, cur_patch, cur_next + rank);
+        if (p.x < C.width && p.y < C.height) {  // a slot outside the frame is used up without a pixel
+          busy = true;
+          my_patch = cur_patch;
+          my_slot = cur_next + rank;
+          color = {0, 0, 0};
+          sp = 0;
+          if (S.max_depth == 0) {
+            color = ld3(S.ambient);  // trace_inner(depth 0 >= MAX_DEPTH)
+          } else {
+            const V3 dir = camera_ray_direction(C, p.x, p.y);  // cameras.rs:52-69
+            StackEntry& e = stack[sp++];
+            e.ox = origin.x, e.oy = origin.y, e.oz = origin.z;
+            e.dx = dir.x, e.dy = dir.y, e.dz = dir.z;
+            e.weight = 1.0;
+            e.depth = 0;
+          }
+        }
+      }
+      cur_next += take;
+    }
+    if (!__any(busy)) break;  // nothing left to hand out and every pixel stored
+
+    // one node per lane
+    const bool have = busy && sp > 0;
+    V3 ro = {0, 0, 0}, rd = {0, 0, 1};
+    double weight = 0.0;
+    int depth = 0;
+    if (have) {
+      --sp;
+      const StackEntry& e = stack[sp];
+      ro = {e.ox, e.oy, e.oz};
+      rd = {e.dx, e.dy, e.dz};
+      weight = e.weight;
+      depth = e.depth;
+    }
+    if (__any(have))
+      trace_step<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, weight, depth, stack, sp, color,
+                                                      c_primary, c_shadow, c_secondary, c_exact);
+
+    // pixels whose tree is done
+    if (busy && sp == 0) {
+      store_pixel(C, T, pixel_slot(T, my_patch, my_slot), color);
+      busy = false;
+    }
+  }
 
   // ray counters: one atomic per wavefront
   c_primary = wave_sum(c_primary);
@@ -474,14 +620,13 @@ __global__ void __launch_bounds__(kBlock) untile_sampled_kernel(uint32_t width, 
 constexpr uint32_t kWideScene = 256;
 
 template <bool WIDE, bool TRACK>
-static hipError_t launch_render_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, const DevCamera& C,
-                                   const float4* prim, const float4* prim_cluster, const RenderTarget& T,
-                                   DevCounters* counters) {
+static hipError_t launch_render_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, const DevCamera& C, const RenderTarget& T,
+                                   DevCounters* counters, unsigned int* work) {
   switch (lb) {
-    case 1: hipLaunchKernelGGL((render_kernel<true, 1, WIDE, false, TRACK>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
-    case 2: hipLaunchKernelGGL((render_kernel<true, 2, WIDE, false, TRACK>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
-    case 4: hipLaunchKernelGGL((render_kernel<true, 4, WIDE, false, TRACK>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
-    default: hipLaunchKernelGGL((render_kernel<true, 8, WIDE, false, TRACK>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters); break;
+    case 1: hipLaunchKernelGGL((render_kernel<1, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, counters, work); break;
+    case 2: hipLaunchKernelGGL((render_kernel<2, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, counters, work); break;
+    case 4: hipLaunchKernelGGL((render_kernel<4, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, counters, work); break;
+    default: hipLaunchKernelGGL((render_kernel<8, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, counters, work); break;
   }
   return hipGetLastError();
 }
@@ -502,26 +647,32 @@ hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamer
   return hipGetLastError();
 }
 
-hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
-                         const float4* prim_cluster, const RenderTarget& T, DevCounters* counters) {
+hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const RenderTarget& T, DevCounters* counters) {
   if (T.n_local_tiles == 0) return hipSuccess;
-  dim3 grid(T.n_local_tiles);
   // TRACK kernels (some refractive index differs from the others) carry the entry before the winner
   // and the literal n1 evaluation; the others drop both
   const bool track = S.track_n1 != 0;
   if (S.n_objects <= kBruteObjects) {
     if (track)
-      hipLaunchKernelGGL((render_kernel<true, 1, false, true, true>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters);
+      hipLaunchKernelGGL((render_small_kernel<true>), dim3(T.n_local_tiles), dim3(kBlock), 0, st, S, C, T, counters);
     else
-      hipLaunchKernelGGL((render_kernel<true, 1, false, true, false>), grid, dim3(kBlock), 0, st, S, C, prim, prim_cluster, T, counters);
+      hipLaunchKernelGGL((render_small_kernel<false>), dim3(T.n_local_tiles), dim3(kBlock), 0, st, S, C, T, counters);
     return hipGetLastError();
   }
+  // Persistent wavefronts draw 8x8 patches from the launch's work counter (the word behind the
+  // counter shards): enough workgroups to fill the GPU
+  // twice over at four wavefronts per SIMD, no more than there are tiles.
+  unsigned int* work = reinterpret_cast<unsigned int*>(counters + kCounterShards);
+  // a frame may be made of several launches that share the counters: each starts its patches at zero
+  hipError_t e = hipMemsetAsync(work, 0, sizeof(unsigned int), st);
+  if (e != hipSuccess) return e;
+  dim3 grid(std::min<uint32_t>(T.n_local_tiles, kPersistentGroups));
   const int lb = light_batch_for(S.n_lights);
   if (S.n_spheres >= kWideScene)
-    return track ? launch_render_lb<true, true>(lb, grid, st, S, C, prim, prim_cluster, T, counters)
-                 : launch_render_lb<true, false>(lb, grid, st, S, C, prim, prim_cluster, T, counters);
-  return track ? launch_render_lb<false, true>(lb, grid, st, S, C, prim, prim_cluster, T, counters)
-               : launch_render_lb<false, false>(lb, grid, st, S, C, prim, prim_cluster, T, counters);
+    return track ? launch_render_lb<true, true>(lb, grid, st, S, C, T, counters, work)
+                 : launch_render_lb<true, false>(lb, grid, st, S, C, T, counters, work);
+  return track ? launch_render_lb<false, true>(lb, grid, st, S, C, T, counters, work)
+               : launch_render_lb<false, false>(lb, grid, st, S, C, T, counters, work);
 }
 
 template <bool WIDE, bool TRACK>

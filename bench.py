@@ -116,6 +116,12 @@ def main():
                          "(a functional rehearsal of the multi-GPU frame, not a scaling measurement)")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout: libraries that print to the C-level stdout (RCCL announces its version
+    # there when a communicator comes up) are sent to stderr; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as tdist
 
@@ -328,7 +334,8 @@ def main():
             out["other_configs_kernel_only"] = extra
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rtk, scene, camera)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if in_process_group:
         grp.close()

@@ -671,9 +671,9 @@ __device__ __forceinline__ V3 shade_hit_stashed(const DevScene& S, uint32_t obj,
 }
 
 // All three steps in one kernel (every light has w = 0 or 1): no hit records cross HBM.
-// Five wavefronts per SIMD (96 VGPRs): with the object records in scalar registers the kernel
-// spills 88 bytes per lane there and still runs faster than at four wavefronts without spills
-// (C4 0.83 against 0.86 ms, a 4096^2 C5 1.39 against 1.48); six wavefronts lose again.
+// Five wavefronts per SIMD: with the object records in scalar registers the kernel needs 89 VGPRs
+// and no scratch (built without machine LICM, see the Makefile); C4 0.78 ms against 0.86 at four
+// wavefronts, a 4096^2 C5 1.31 against 1.48.  Six wavefronts spill 88 bytes per lane for no gain.
 template <int KW, bool TABULATED>
 __global__ void __launch_bounds__(kBlock, 5) render_uniform_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                                   const float4* __restrict__ prim_ball,

@@ -52,6 +52,8 @@ enum { RTK_TEX_SOLID = 0, RTK_TEX_CHECKER = 1, RTK_TEX_GRADIENT = 2, RTK_TEX_RIN
 #define RTK_REFERENCE_MAX_DEPTH 5
 /* Largest max_depth the device path accepts (bounds the per-pixel ray stack). */
 #define RTK_MAX_DEPTH_LIMIT 8
+/* Most lights a scene may hold (`Scene::add_light`, src/scene.rs:131-133, has no limit of its own). */
+#define RTK_MAX_LIGHTS 32767
 /* Frame tile used for the multi-GPU partition: RTK_TILE_W x RTK_TILE_H pixels. */
 #define RTK_TILE_W 32
 #define RTK_TILE_H 8
@@ -187,7 +189,7 @@ void rtk_destroy(rtk_context* ctx);
  *  - object and camera transforms are affine (last row 0 0 0 1), as every constructor
  *    in src/maths/transforms.rs produces;
  *  - plane_normal[3] == 0 (the loader always passes vec3(0,1,0), src/loader.rs:90);
- *  - max_depth <= RTK_MAX_DEPTH_LIMIT, n_lights <= 64. */
+ *  - max_depth <= RTK_MAX_DEPTH_LIMIT, n_lights <= RTK_MAX_LIGHTS. */
 int rtk_scene_upload(rtk_context* ctx, const rtk_scene* scene, rtk_scene_handle** out);
 void rtk_scene_release(rtk_context* ctx, rtk_scene_handle* scene);
 

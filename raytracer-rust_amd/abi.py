@@ -25,6 +25,7 @@ RTK_TEX_STRIPED = 4
 
 RTK_REFERENCE_MAX_DEPTH = 5
 RTK_MAX_DEPTH_LIMIT = 8
+RTK_MAX_LIGHTS = 32767
 RTK_TIMING_HISTORY = 64
 RTK_MAX_SAMPLES_PER_AXIS = 16
 RTK_TILE_W = 32

@@ -51,7 +51,7 @@ using rtk::fail_hip;
 //   prim_cluster  RTK_STATIC_MAX_SPHERES / 64 x float4  ... of the cluster balls
 //   hit_t         RTK_STATIC_MAX_RECORD_PIXELS x f64  hit records of the three-kernel path
 //   hit_obj       RTK_STATIC_MAX_RECORD_PIXELS x u32
-//   shadow        RTK_STATIC_MAX_RECORD_PIXELS x u8
+//   shadow        RTK_STATIC_MAX_RECORD_PIXELS x u16
 namespace {
 constexpr size_t kStaticCounters = 0;
 constexpr size_t kStaticPrim = (kStaticCounters + sizeof(rtk::DevCounters) * rtk::kCounterSlots + 255u) & ~(size_t)255u;
@@ -60,7 +60,7 @@ constexpr size_t kStaticPrimCluster = kStaticPrimBall + (size_t)RTK_STATIC_MAX_S
 constexpr size_t kStaticHitT = kStaticPrimCluster + (size_t)RTK_STATIC_MAX_SPHERES / rtk::kBundle * sizeof(float4);
 constexpr size_t kStaticHitObj = kStaticHitT + (size_t)RTK_STATIC_MAX_RECORD_PIXELS * sizeof(double);
 constexpr size_t kStaticShadow = kStaticHitObj + (size_t)RTK_STATIC_MAX_RECORD_PIXELS * sizeof(uint32_t);
-constexpr size_t kStaticEnd = kStaticShadow + (size_t)RTK_STATIC_MAX_RECORD_PIXELS;
+constexpr size_t kStaticEnd = kStaticShadow + (size_t)RTK_STATIC_MAX_RECORD_PIXELS * sizeof(uint16_t);
 static_assert(kStaticEnd <= RTK_STATIC_SCRATCH_BYTES, "static scratch layout exceeds RTK_STATIC_SCRATCH_BYTES");
 static_assert(kStaticPrim % 256 == 0 && kStaticHitT % 256 == 0 && kStaticHitObj % 256 == 0 && kStaticShadow % 256 == 0,
               "pieces of the static scratch are 256-byte aligned");
@@ -424,7 +424,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   if ((scene->n_objects && !scene->objects) || (scene->n_lights && !scene->lights))
     return fail(RTK_ERR_INVALID, "rtk_scene_upload: null object or light array");
   if (scene->max_depth > RTK_MAX_DEPTH_LIMIT) return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: max_depth above RTK_MAX_DEPTH_LIMIT");
-  if (scene->n_lights > 64) return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: more than 64 lights");
+  if (scene->n_lights > RTK_MAX_LIGHTS) return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: more than RTK_MAX_LIGHTS (32,767) lights");
 
   using namespace rtk;
   // Upper bound of the staged bytes (every piece rounded up to 256): the object array is built in
@@ -908,7 +908,7 @@ static int context_records(rtk_context* ctx, size_t pixels, rtk::OpaqueBuffers& 
     ctx->cap_opaque = 0;
     RTK_HIP(hipMalloc((void**)&ctx->opaque.hit_obj, pixels * sizeof(uint32_t)));
     RTK_HIP(hipMalloc((void**)&ctx->opaque.hit_t, pixels * sizeof(double)));
-    RTK_HIP(hipMalloc((void**)&ctx->opaque.shadow, pixels));
+    RTK_HIP(hipMalloc((void**)&ctx->opaque.shadow, pixels * sizeof(uint16_t)));
     ctx->cap_opaque = pixels;
   }
   out = ctx->opaque;
@@ -1048,7 +1048,7 @@ int rtk_render_device_static(rtk_context* ctx, rtk_scene_handle* scene, const rt
   if (records) {
     scr.opaque.hit_t = (double*)(base + kStaticHitT);
     scr.opaque.hit_obj = (uint32_t*)(base + kStaticHitObj);
-    scr.opaque.shadow = (uint8_t*)(base + kStaticShadow);
+    scr.opaque.shadow = (uint16_t*)(base + kStaticShadow);
   }
   // from here on: stream waits, a memset of the counters, kernel launches and event records -- no allocation
   Frame f;

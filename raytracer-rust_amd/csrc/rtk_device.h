@@ -12,6 +12,7 @@ constexpr int kBlock = 256;      // threads per workgroup = one 32x8 pixel tile 
 constexpr int kGroup = 8;        // records per wavefront early-out branch (one ray per lane)
 constexpr int kBundle = 64;      // records per wavefront-level test (one sphere per lane); arrays are padded to this
 constexpr int kMaxDepth = 8;     // == RTK_MAX_DEPTH_LIMIT
+constexpr uint32_t kMaxLights = 32767;  // == RTK_MAX_LIGHTS: the shadow-ray count of a hit is kept in 15 bits
 
 constexpr float kEps32 = 5.9604645e-8f;  // 2^-24, unit round-off of FP32
 
@@ -129,7 +130,7 @@ __device__ __forceinline__ DevCounters* counter_shard(DevCounters* base) { retur
 struct OpaqueBuffers {
   uint32_t* hit_obj;  // object index of the closest hit, 0xffffffff = miss
   double* hit_t;      // its ray parameter
-  uint8_t* shadow;    // bit 7: in shadow; bits 0..6: shadow rays the reference traces for this hit
+  uint16_t* shadow;   // bit 15: in shadow; bits 0..14: shadow rays the reference traces for this hit
 };
 
 struct RenderTarget {

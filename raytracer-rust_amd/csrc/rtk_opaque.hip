@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(kBlock, 4) shadow_general_kernel(DevScene S, D
   if (hit) p = over_point(S, C, px, obj, B.hit_t[px.local]);
   unsigned rays = 0, n_exact = 0;
   const bool in_shadow = shadow_sweeps<LB, false>(S, hit, p, rays, n_exact);
-  B.shadow[px.local] = (uint8_t)((in_shadow ? 0x80u : 0u) | rays);
+  B.shadow[px.local] = (uint16_t)((in_shadow ? 0x8000u : 0u) | rays);
   n_exact = wave_sum(n_exact);
   if ((threadIdx.x & 63u) == 0) atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
 }
@@ -647,9 +647,9 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, 
     color = ld3(S.ambient);  // a miss, or trace_inner at depth >= MAX_DEPTH, returns ambient_color
     const uint32_t obj = B.hit_obj[px.local];
     if (obj != 0xffffffffu) {
-      const uint8_t sh = B.shadow[px.local];
-      n_shadow = sh & 0x7fu;
-      color = shade_hit(S, C, px, obj, B.hit_t[px.local], (sh & 0x80u) != 0);
+      const uint16_t sh = B.shadow[px.local];
+      n_shadow = sh & 0x7fffu;
+      color = shade_hit(S, C, px, obj, B.hit_t[px.local], (sh & 0x8000u) != 0);
     }
   }
   store_tile(C, T, k, color, s_rgb, s_px);

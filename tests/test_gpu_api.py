@@ -42,10 +42,11 @@ def test_unsupported_inputs_are_rejected(rtk, dev, device_mod):
     scene.max_depth = rtk.abi.RTK_MAX_DEPTH_LIMIT + 1
     with pytest.raises(device_mod.RtkError):
         dev.upload(scene)
-    scene = rtk.synthetic.make_scene(4, True, 65, 99)  # one light more than the library takes
+    s = rtk.synthetic.make_scene(4, True, 2, 99).to_abi()
+    s.n_lights = rtk.abi.RTK_MAX_LIGHTS + 1  # one light more than the library takes (the count is checked before the array is read)
     with pytest.raises(device_mod.RtkError) as e:
-        dev.upload(scene)
-    assert e.value.code == rtk.abi.RTK_ERR_UNSUPPORTED and "64 lights" in str(e.value)
+        dev.upload(s)
+    assert e.value.code == rtk.abi.RTK_ERR_UNSUPPORTED and "RTK_MAX_LIGHTS" in str(e.value)
     scene, _ = rtk.synthetic.config("C2", 64, 36)
     scene.nodes[0].plane_normal = (0.0, 1.0, 0.0, 0.5)
     with pytest.raises(device_mod.RtkError):

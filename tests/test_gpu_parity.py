@@ -647,12 +647,13 @@ def test_largest_configuration_crops(rtk, dev, oracle):
     h.release()
 
 
-def test_the_largest_light_count(rtk, dev, oracle):
-    """64 lights, the most the library takes: sixteen batches of four, both with scene-file lights
-    (w = 0) and with lights built from points (w = 1)."""
-    for w in (0.0, 1.0):
-        scene = rtk.synthetic.make_scene(30, True, 64, 4321)
+def test_many_lights(rtk, dev, oracle):
+    """`Scene::add_light` (src/scene.rs:131-133) has no limit: 64 and 300 lights, as scene-file lights
+    (w = 0, 16 / 75 batches of four), as lights built from points (w = 1), and with w = 0.5, which sends
+    the frame down the three-kernel path whose hit records count a hit's shadow rays in 15 bits."""
+    for n_lights, w, size in ((64, 0.0, (160, 90)), (64, 1.0, (160, 90)), (300, 0.0, (96, 54)), (300, 1.0, (96, 54)), (300, 0.5, (96, 54))):
+        scene = rtk.synthetic.make_scene(30, True, n_lights, 4321)
         scene.lights = [rtk.PointLight(rtk.vec4(*l.position[:3], w), l.intensity) for l in scene.lights]
-        camera = rtk.synthetic.make_camera(30, 160, 90)
-        canvas = check_against_oracle(dev, oracle, scene, camera, f"64 lights, w = {w}")
-        assert canvas.stats.rays_shadow <= 64 * canvas.stats.rays_primary
+        camera = rtk.synthetic.make_camera(30, *size)
+        canvas = check_against_oracle(dev, oracle, scene, camera, f"{n_lights} lights, w = {w}")
+        assert canvas.stats.rays_shadow <= n_lights * canvas.stats.rays_primary

@@ -175,7 +175,7 @@ def main():
         outs = [(torch.empty((camera.height, camera.width, 3), dtype=torch.float32, device=grp.tdev),
                  torch.empty((camera.height, camera.width, 4), dtype=torch.uint8, device=grp.tdev)) for _ in range(2)]
         partition = (f"bands of {grp.band_tile_rows(camera.height)} tile rows (8 px each) dealt round-robin to {args.gpus} members of "
-                     "one process; FP32 RGB + RGBA8 rows sent with ncclSend and received in place on member 0"
+                     "one process; FP32 RGB + RGBA8 rows land in place on member 0 (exchange: " + grp.exchange() + ")"
                      + (" (loopback: all members on device 0)" if args.loopback else ""))
 
         def run(n):  # two frames in flight: output buffers and the members' band buffers alternate
@@ -295,7 +295,8 @@ def main():
                 if avg_kernel_ms > 0 else None,  # sanity counter: 12 B FP32 RGB + 4 B RGBA8 per pixel, written once
                 "note": "achieved = f64 flops the kernel executes per launch (PMC instruction mix x 64 lanes x share of lanes "
                         "active; fma = 2) / HIP-event time of that kernel in this run; peak = vector f64 peak (256 CUs x 2.4 GHz x "
-                        "128 flop/clk/CU). The kernel is bound by dependent-load latency at 4 waves per SIMD, not by arithmetic",
+                        "128 flop/clk/CU). The kernel is bound by instruction issue (VALU busy ~3/4 of cycles, a third of them moves, selects and "
+                        "compares) and dependent-load latency at 5 waves per SIMD, not by f64 arithmetic",
             },
             "reference_sweep_equivalent": {
                 "flops_per_ray": fpr,

@@ -330,11 +330,17 @@ int rtk_get_timing_history(rtk_context* ctx, uint32_t capacity, double* kernel_m
  * device_ids may name a device more than once: such members share that device's communicator
  * and exchange through RCCL's send-to-self, which lets a one-GPU machine run every step of the
  * multi-GPU frame.  librccl.so.1 is loaded when the first group is created; a group of one
- * member needs no exchange and does not load it. */
+ * member needs no exchange and does not load it.  If RCCL cannot be loaded or its communicators
+ * do not come up, the same bands travel as peer-to-peer copies (hipMemcpyPeerAsync, one per
+ * band, on the sending member's stream) into the same final rows.  The environment variable
+ * RTK_GROUP_EXCHANGE, read by rtk_group_create, overrides the choice: "rccl" (RTK_ERR_RCCL
+ * rather than a fall-back) or "peer" (copies from the start). */
 typedef struct rtk_group rtk_group;
 int rtk_group_create(const int* device_ids, int n_members, rtk_group** out);
 void rtk_group_destroy(rtk_group* group);
 int rtk_group_size(const rtk_group* group);
+/* How the members' rows reach the root: "rccl", "peer copies", or "none" (a group of one). */
+const char* rtk_group_exchange(const rtk_group* group);
 /* Flattens the scene once and copies it to every member's device (replacing the group's
  * previous scene, if any). */
 int rtk_group_upload(rtk_group* group, const rtk_scene* scene);
@@ -350,6 +356,10 @@ int rtk_group_render_device(rtk_group* group, const rtk_camera* camera, float* d
 int rtk_group_get_stats(rtk_group* group, rtk_stats* stats);
 /* Tile rows per band the group uses for a frame of `height` pixel rows. */
 uint32_t rtk_group_band_tile_rows(const rtk_group* group, uint32_t height);
+/* How many bands of a frame each member gets (about; a band is a whole number of tile rows):
+ * more bands even out rows that cost differently, fewer mean fewer, larger messages to the root.
+ * 0 restores the library's choice.  Takes effect from the next frame. */
+int rtk_group_set_bands_per_member(rtk_group* group, uint32_t bands_per_member);
 
 /* Thread-local description of the last failure on this thread ("" if none). */
 const char* rtk_last_error(void);

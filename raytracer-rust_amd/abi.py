@@ -193,6 +193,8 @@ SYMBOLS = {
     "rtk_group_render_device": (C.c_int, [C.c_void_p, C.POINTER(rtk_camera), C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtk_group_get_stats": (C.c_int, [C.c_void_p, C.POINTER(rtk_stats)]),
     "rtk_group_band_tile_rows": (C.c_uint32, [C.c_void_p, C.c_uint32]),
+    "rtk_group_set_bands_per_member": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rtk_group_exchange": (C.c_char_p, [C.c_void_p]),
     "rtk_last_error": (C.c_char_p, []),
     "rtk_version": (C.c_char_p, []),
 }

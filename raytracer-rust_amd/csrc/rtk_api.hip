@@ -927,8 +927,7 @@ static int frame_begin(Frame& f, rtk_context* ctx, rtk_scene_handle* scene, cons
   f.opaque = !scene->dev.any_secondary;
   if (ctx->n_timed && ctx->last_stream != f.st)
     RTK_HIP(hipStreamWaitEvent(f.st, ctx->ev_stop[(ctx->n_timed - 1) % RTK_TIMING_HISTORY], 0));
-  RTK_HIP(hipMemsetAsync(f.scr.counters, 0, sizeof(rtk::DevCounters) * rtk::kCounterSlots, f.st));
-  RTK_HIP(rtk::launch_prep_primary(f.st, scene->dev, f.cam, f.scr.prim, f.scr.prim_ball, f.scr.prim_cluster));
+  RTK_HIP(rtk::launch_prep_primary(f.st, scene->dev, f.cam, f.scr.prim, f.scr.prim_ball, f.scr.prim_cluster, f.scr.counters));
   f.slot = (int)(ctx->n_timed % RTK_TIMING_HISTORY);
   RTK_HIP(hipEventRecord(ctx->ev_start[f.slot], f.st));  // the per-camera record kernel (microseconds) stays outside
   ctx->ev_split[f.slot] = false;

@@ -11,7 +11,10 @@
 // peer's own link to the root.
 //
 // librccl is loaded at run time, when the first group of more than one member is created: a
-// single-GPU user of the library never pays for loading it.
+// single-GPU user of the library never pays for loading it.  Where it cannot be loaded or its
+// communicators do not come up, the same bands travel as peer-to-peer copies
+// (hipMemcpyPeerAsync on the sending member's communication stream) instead; RTK_GROUP_EXCHANGE
+// = "rccl" (fail rather than fall back) or "peer" (copies from the start) overrides the choice.
 
 #include "rtk_internal.h"
 
@@ -20,6 +23,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -106,6 +110,8 @@ struct rtk_group {
   std::vector<DeviceSlot> slots;
   std::vector<Member> members;
   uint64_t frame = 0;
+  uint32_t bands_per_member = 0;  // 0: the library's choice
+  bool use_rccl = false;          // else peer-to-peer copies
   hipEvent_t ev_enter = nullptr;                // the caller's stream has reached the call
   hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;  // the exchange of the last frame on the root's communication stream
   bool exchanged = false;                       // ... was there one
@@ -114,10 +120,16 @@ struct rtk_group {
 
 namespace {
 
-uint32_t band_tile_rows_for(size_t n_members, uint32_t height) {
-  // about 32 bands per member: enough to mix sky and ground rows evenly, few enough sends per frame
+// Bands per member unless the caller chooses: enough to mix cheap sky rows and expensive ground
+// rows (10,000-sphere scene at 3840x2160 on 8 members: the slowest member's kernels take 0.145 ms
+// with 4 bands each, 0.129 ms with 32), few enough messages per frame (a send/receive pair costs
+// RCCL about 6 us on top of its bytes: 0.5 ms per frame with 4 bands each, 3 ms with 32).
+constexpr uint32_t kBandsPerMember = 4;
+
+uint32_t band_tile_rows_for(const rtk_group* g, uint32_t height) {
+  const uint32_t per_member = g->bands_per_member ? g->bands_per_member : kBandsPerMember;
   const uint32_t tiles_y = (height + RTK_TILE_H - 1) / RTK_TILE_H;
-  return std::max<uint32_t>(1u, (uint32_t)(tiles_y / (n_members * 32u)));
+  return std::max<uint32_t>(1u, (uint32_t)(tiles_y / (g->members.size() * (size_t)per_member)));
 }
 
 void release_scenes(rtk_group* g) {
@@ -180,21 +192,44 @@ int rtk_group_create(const int* device_ids, int n_members, rtk_group** out) {
       m.slot = slot;
     }
     if (rc == RTK_OK && n_members > 1) {
-      rc = load_rccl();
-      if (rc == RTK_OK) {
-        // one communicator per distinct device, ranks in order of first appearance
-        std::vector<int> devices;
-        for (const DeviceSlot& s : g->slots) devices.push_back(s.device);
-        std::vector<ncclComm_t> comms(devices.size(), nullptr);
-        const ncclResult_t e = g_rccl.CommInitAll(comms.data(), (int)devices.size(), devices.data());
-        if (e != ncclSuccess) rc = fail_rccl(e, "ncclCommInitAll");
-        for (size_t s = 0; s < g->slots.size() && rc == RTK_OK; ++s) {
-          g->slots[s].comm = comms[s];
-          g->slots[s].comm_rank = (int)s;
-          hipError_t he = hipSetDevice(g->slots[s].device);
-          if (he == hipSuccess) he = hipStreamCreateWithFlags(&g->slots[s].comm_stream, hipStreamNonBlocking);
-          if (he != hipSuccess) rc = fail_hip(he, "rtk_group_create: communication stream");
+      const char* want = std::getenv("RTK_GROUP_EXCHANGE");
+      const bool force_rccl = want && std::strcmp(want, "rccl") == 0, force_peer = want && std::strcmp(want, "peer") == 0;
+      if (want && *want && !force_rccl && !force_peer)
+        rc = fail(RTK_ERR_INVALID, "rtk_group_create: RTK_GROUP_EXCHANGE must be \"rccl\" or \"peer\"");
+      if (rc == RTK_OK && !force_peer) {
+        rc = load_rccl();
+        std::vector<ncclComm_t> comms(g->slots.size(), nullptr);
+        if (rc == RTK_OK) {
+          // one communicator per distinct device, ranks in order of first appearance
+          std::vector<int> devices;
+          for (const DeviceSlot& s : g->slots) devices.push_back(s.device);
+          const ncclResult_t e = g_rccl.CommInitAll(comms.data(), (int)devices.size(), devices.data());
+          if (e != ncclSuccess) rc = fail_rccl(e, "ncclCommInitAll");
         }
+        if (rc == RTK_OK) {
+          g->use_rccl = true;
+          for (size_t s = 0; s < g->slots.size(); ++s) g->slots[s].comm = comms[s], g->slots[s].comm_rank = (int)s;
+        } else if (!force_rccl) {
+          rc = RTK_OK;  // peer-to-peer copies need nothing but HIP
+        }
+      }
+      for (size_t s = 0; s < g->slots.size() && rc == RTK_OK; ++s) {
+        hipError_t he = hipSetDevice(g->slots[s].device);
+        if (he == hipSuccess) he = hipStreamCreateWithFlags(&g->slots[s].comm_stream, hipStreamNonBlocking);
+        // copies between two devices: each must be allowed to address the other's memory
+        for (size_t o = 0; o < g->slots.size() && he == hipSuccess && !g->use_rccl; ++o) {
+          if (o == s) continue;
+          int can = 0;
+          he = hipDeviceCanAccessPeer(&can, g->slots[s].device, g->slots[o].device);
+          if (he == hipSuccess && can) {
+            he = hipDeviceEnablePeerAccess(g->slots[o].device, 0);
+            if (he == hipErrorPeerAccessAlreadyEnabled) {
+              (void)hipGetLastError();
+              he = hipSuccess;
+            }
+          }
+        }
+        if (he != hipSuccess) rc = fail_hip(he, "rtk_group_create: communication stream");
       }
       for (int r = 0; r < n_members && rc == RTK_OK; ++r) {
         Member& m = g->members[(size_t)r];
@@ -259,9 +294,21 @@ void rtk_group_destroy(rtk_group* g) {
 
 int rtk_group_size(const rtk_group* g) { return g ? (int)g->members.size() : 0; }
 
+const char* rtk_group_exchange(const rtk_group* g) {
+  if (!g || g->members.size() < 2) return "none";
+  return g->use_rccl ? "rccl" : "peer copies";
+}
+
 uint32_t rtk_group_band_tile_rows(const rtk_group* g, uint32_t height) {
   if (!g || height == 0) return 0;
-  return band_tile_rows_for(g->members.size(), height);
+  return band_tile_rows_for(g, height);
+}
+
+int rtk_group_set_bands_per_member(rtk_group* g, uint32_t bands_per_member) {
+  if (!g) return fail(RTK_ERR_INVALID, "rtk_group_set_bands_per_member: null group");
+  if (bands_per_member > 65536u) return fail(RTK_ERR_INVALID, "rtk_group_set_bands_per_member: more than 65,536 bands per member");
+  g->bands_per_member = bands_per_member;
+  return RTK_OK;
 }
 
 int rtk_group_upload(rtk_group* g, const rtk_scene* scene) {
@@ -294,7 +341,7 @@ int rtk_group_render_device(rtk_group* g, const rtk_camera* camera, float* d_rgb
     return rtk_render_device(root.ctx, root.scene, camera, nullptr, d_rgb_f32, d_rgba8, st0);
   }
   const uint32_t width = camera->width, height = camera->height;
-  const uint32_t m_rows = band_tile_rows_for(n, height);
+  const uint32_t m_rows = band_tile_rows_for(g, height);
   const uint32_t tiles_y = (height + RTK_TILE_H - 1) / RTK_TILE_H;
   const uint32_t n_bands = (tiles_y + m_rows - 1) / m_rows;
   const int b = (int)(g->frame & 1u);
@@ -335,16 +382,25 @@ int rtk_group_render_device(rtk_group* g, const rtk_camera* camera, float* d_rgb
   g->exchanged = exchange;
   if (exchange) {
     RTK_HIP(hipEventRecord(g->ev_x0, slot0.comm_stream));
-    RTK_RCCL(g_rccl.GroupStart());
-    ncclResult_t first_bad = ncclSuccess;
-    for (size_t r = 1; r < n && first_bad == ncclSuccess; ++r) {
-      Member& m = g->members[r];
-      DeviceSlot& slot = g->slots[(size_t)m.slot];
-      size_t local_row = 0;  // pixel rows of this member's buffer consumed so far
-      for (uint32_t band = (uint32_t)r; band < n_bands && first_bad == ncclSuccess; band += (uint32_t)n) {
-        const uint32_t t0 = band * m_rows, t1 = std::min(tiles_y, t0 + m_rows);
-        const size_t y0 = (size_t)t0 * RTK_TILE_H, y1 = std::min<size_t>(height, (size_t)t1 * RTK_TILE_H);
-        const size_t count = (y1 - y0) * width, from = local_row * width, to = y0 * width;
+    // Visits every band of every other member: where it lies in the member's buffer (`from`), where
+    // its rows go in the frame (`to`), both in pixels.
+    auto for_each_band = [&](auto&& visit) {
+      for (size_t r = 1; r < n; ++r) {
+        size_t local_row = 0;  // pixel rows of this member's buffer consumed so far
+        for (uint32_t band = (uint32_t)r; band < n_bands; band += (uint32_t)n) {
+          const uint32_t t0 = band * m_rows, t1 = std::min(tiles_y, t0 + m_rows);
+          const size_t y0 = (size_t)t0 * RTK_TILE_H, y1 = std::min<size_t>(height, (size_t)t1 * RTK_TILE_H);
+          if (!visit(g->members[r], (y1 - y0) * width, local_row * width, y0 * width)) return false;
+          local_row += (size_t)(t1 - t0) * RTK_TILE_H;
+        }
+      }
+      return true;
+    };
+    if (g->use_rccl) {
+      RTK_RCCL(g_rccl.GroupStart());
+      ncclResult_t first_bad = ncclSuccess;
+      for_each_band([&](Member& m, size_t count, size_t from, size_t to) {
+        DeviceSlot& slot = g->slots[(size_t)m.slot];
         if (d_rgb_f32) {
           first_bad = g_rccl.Send(m.band_rgb[b] + from * 3, count * 3, ncclFloat, slot0.comm_rank, slot.comm, slot.comm_stream);
           if (first_bad == ncclSuccess)
@@ -355,12 +411,33 @@ int rtk_group_render_device(rtk_group* g, const rtk_camera* camera, float* d_rgb
           if (first_bad == ncclSuccess)
             first_bad = g_rccl.Recv(d_rgba8 + to * 4, count * 4, ncclUint8, slot.comm_rank, slot0.comm, slot0.comm_stream);
         }
-        local_row += (size_t)(t1 - t0) * RTK_TILE_H;
+        return first_bad == ncclSuccess;
+      });
+      const ncclResult_t end = g_rccl.GroupEnd();  // always closes the group, even after a failed call inside it
+      if (first_bad != ncclSuccess) return fail_rccl(first_bad, "ncclSend / ncclRecv");
+      if (end != ncclSuccess) return fail_rccl(end, "ncclGroupEnd");
+    } else {
+      // each member pushes its bands over its own link, on its own communication stream, once the
+      // caller's stream has let go of the frame buffers
+      for (size_t r = 1; r < n; ++r) {
+        Member& m = g->members[r];
+        RTK_HIP(hipSetDevice(m.ctx->device));
+        RTK_HIP(hipStreamWaitEvent(g->slots[(size_t)m.slot].comm_stream, g->ev_enter, 0));
       }
+      hipError_t first_bad = hipSuccess;
+      const int root_device = root.ctx->device;
+      for_each_band([&](Member& m, size_t count, size_t from, size_t to) {
+        hipStream_t cs = g->slots[(size_t)m.slot].comm_stream;
+        first_bad = hipSetDevice(m.ctx->device);
+        if (d_rgb_f32 && first_bad == hipSuccess)
+          first_bad = hipMemcpyPeerAsync(d_rgb_f32 + to * 3, root_device, m.band_rgb[b] + from * 3, m.ctx->device,
+                                         count * 3 * sizeof(float), cs);
+        if (d_rgba8 && first_bad == hipSuccess)
+          first_bad = hipMemcpyPeerAsync(d_rgba8 + to * 4, root_device, m.band_px[b] + from * 4, m.ctx->device, count * 4, cs);
+        return first_bad == hipSuccess;
+      });
+      if (first_bad != hipSuccess) return fail_hip(first_bad, "hipMemcpyPeerAsync");
     }
-    const ncclResult_t end = g_rccl.GroupEnd();  // always closes the group, even after a failed call inside it
-    if (first_bad != ncclSuccess) return fail_rccl(first_bad, "ncclSend / ncclRecv");
-    if (end != ncclSuccess) return fail_rccl(end, "ncclGroupEnd");
     for (size_t r = 1; r < n; ++r) {
       Member& m = g->members[r];
       RTK_HIP(hipSetDevice(m.ctx->device));
@@ -368,6 +445,8 @@ int rtk_group_render_device(rtk_group* g, const rtk_camera* camera, float* d_rgb
       m.sent_valid[b] = true;
     }
     RTK_HIP(hipSetDevice(root.ctx->device));
+    if (!g->use_rccl)  // the copies ran on the members' streams: the root's waits for each of them
+      for (size_t r = 1; r < n; ++r) RTK_HIP(hipStreamWaitEvent(slot0.comm_stream, g->members[r].ev_sent[b], 0));
     RTK_HIP(hipEventRecord(g->ev_x1, slot0.comm_stream));
     RTK_HIP(hipStreamWaitEvent(st0, g->ev_x1, 0));  // the caller's stream sees the whole frame
   }

@@ -9,10 +9,11 @@ namespace rtk {
 // Lights fused per shadow sweep for a scene with n_lights lights (1, 2, 4 or 8).
 int light_batch_for(uint32_t n_lights);
 
-// Rebuilds the camera-ray records for camera C: prim[n_spheres_padded] (per-ray filter) and
-// prim_ball[n_spheres_padded] and prim_cluster[n_clusters_padded] (wavefront-level cone tests).
+// Start of a frame: rebuilds the camera-ray records for camera C -- prim[n_spheres_padded] (per-ray
+// filter), prim_ball[n_spheres_padded] and prim_cluster[n_clusters_padded] (wavefront-level cone
+// tests) -- and clears the frame's counters (kCounterSlots elements).
 hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamera& C, float4* prim, float4* prim_ball,
-                               float4* prim_cluster);
+                               float4* prim_cluster, DevCounters* counters);
 
 // Renders the tiles selected by T.
 // `counters` holds kCounterShards shards followed by one more element whose first word is the

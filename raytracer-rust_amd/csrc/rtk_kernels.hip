@@ -469,8 +469,11 @@ __global__ void __launch_bounds__(kBlock) trace_rays_kernel(DevScene S, const do
 // Per-camera records of the camera-ray tests: one thread per (padded) sphere.
 __global__ void __launch_bounds__(kBlock) prep_primary_kernel(DevScene S, DevCamera C, float4* __restrict__ prim,
                                                               float4* __restrict__ prim_ball,
-                                                              float4* __restrict__ prim_cluster) {
+                                                              float4* __restrict__ prim_cluster,
+                                                              unsigned long long* __restrict__ zero, uint32_t n_zero) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  // the frame's ray counters start at zero: cleared here rather than by a fill kernel of their own
+  for (uint32_t z = i; z < n_zero; z += gridDim.x * kBlock) zero[z] = 0ull;
   const double eps = (double)kEps32;
   if (prim_cluster && i < S.n_clusters_padded) {
     // cluster ball as seen from the camera; the ball already contains its members' balls
@@ -639,11 +642,14 @@ int light_batch_for(uint32_t n_lights) {
 }
 
 hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamera& C, float4* prim, float4* prim_ball,
-                               float4* prim_cluster) {
-  if (S.n_spheres_padded == 0) return hipSuccess;
+                               float4* prim_cluster, DevCounters* counters) {
+  constexpr size_t kCounterBytes = sizeof(DevCounters) * kCounterSlots;
+  static_assert(kCounterBytes % sizeof(unsigned long long) == 0, "counters are cleared as 64-bit words");
+  if (S.n_spheres_padded == 0) return hipMemsetAsync(counters, 0, kCounterBytes, st);
   // n_clusters_padded <= n_spheres_padded: one grid covers both record arrays
   dim3 grid((S.n_spheres_padded + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(prep_primary_kernel, grid, dim3(kBlock), 0, st, S, C, prim, prim_ball, prim_cluster);
+  hipLaunchKernelGGL(prep_primary_kernel, grid, dim3(kBlock), 0, st, S, C, prim, prim_ball, prim_cluster,
+                     reinterpret_cast<unsigned long long*>(counters), (uint32_t)(kCounterBytes / sizeof(unsigned long long)));
   return hipGetLastError();
 }
 

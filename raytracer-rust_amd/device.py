@@ -67,6 +67,10 @@ def library():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(the renderer has no CPU fallback)")
+        # PyTorch ships a HIP runtime of its own.  Loaded after librtk.so has brought in the system's,
+        # it finds no device (torch.cuda.is_available() turns False); loaded first, its runtime serves
+        # both.  A host without PyTorch (the C ABI's real caller) has one runtime and no such order.
+        import torch  # noqa: F401
         _lib = abi.bind(C.CDLL(LIB_PATH))
     return _lib
 

@@ -45,6 +45,14 @@ class DeviceGroup:
     def band_tile_rows(self, height):
         return int(_device.library().rtk_group_band_tile_rows(self.group, height))
 
+    def exchange(self):
+        """"rccl", "peer copies" or "none"."""
+        return _device.library().rtk_group_exchange(self.group).decode()
+
+    def set_bands_per_member(self, bands):
+        """About how many bands of a frame each member renders; 0 for the library's choice."""
+        _device._check(_device.library().rtk_group_set_bands_per_member(self.group, int(bands)))
+
     def render_device(self, camera, want_rgb=True, want_rgba8=True, out_rgb=None, out_rgba8=None):
         """Queues one frame; returns ([H, W, 3] float32, [H, W, 4] uint8) tensors on the root's device.
         Asynchronous on torch's current stream of that device."""

@@ -470,7 +470,7 @@ def test_partitions_of_the_benchmark_frames_at_full_size(rtk, dev, name, world):
     del message, f_rgb, f_rgba
     # bands of whole tile rows, written in place
     tiles_y = (h + 7) // 8
-    m = max(1, tiles_y // (world * 32))
+    m = max(1, tiles_y // (world * 4))
     f_rgb = torch.zeros((h, w, 3), dtype=torch.float32, device=dev.tdev) if want_rgb else None
     f_rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev.tdev)
     rays = 0

@@ -23,7 +23,7 @@ SCRIPT = textwrap.dedent(r"""
     group = importlib.import_module("raytracer-rust_amd.group")
     dev = device.Device(0)
 
-    def check(name, w, h, members, frames=5, other_camera=None):
+    def check(name, w, h, members, frames=5, other_camera=None, bands_per_member=0):
         scene, camera = rtk.synthetic.config(name, w, h)
         handle = dev.upload(scene)
         want_rgb, want_rgba = dev.render_device(handle, camera)
@@ -31,7 +31,9 @@ SCRIPT = textwrap.dedent(r"""
         torch.cuda.synchronize()
         g = group.DeviceGroup([0] * members)
         assert len(g) == members
+        assert g.exchange() == ("none" if members == 1 else sys.argv[2])
         g.upload(scene)
+        g.set_bands_per_member(bands_per_member)
         stream = torch.cuda.Stream()
         with torch.cuda.stream(stream):
             outs = [(torch.zeros_like(want_rgb), torch.zeros_like(want_rgba)) for _ in range(2)]
@@ -70,6 +72,8 @@ SCRIPT = textwrap.dedent(r"""
     _, cam2 = rtk.synthetic.config("C3", 320, 200)
     cam2.transform = rtk.Matrix4x4.look_at(rtk.point(20, 9, -30), rtk.point(-5, 0, 25), rtk.vec3(0, 1, 0))
     check("C3", 1920, 1080, 4, other_camera=cam2)
+    check("C3", 1920, 1080, 4, bands_per_member=32)
+    check("C2", 480, 270, 3, bands_per_member=1000)  # bands of one tile row
     check("C2", 40, 9, 4)      # fewer bands than members: some members own nothing
     # a scene replaced on a live group
     g = group.DeviceGroup([0, 0])
@@ -86,10 +90,13 @@ SCRIPT = textwrap.dedent(r"""
 """)
 
 
-def test_group_frames_through_rccl_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("setting,exchange", [("", "rccl"), ("rccl", "rccl"), ("peer", "peer copies")])
+def test_group_frames_on_one_gpu(tmp_path, setting, exchange):
+    """Through RCCL (the default) and through the peer-to-peer copies a group falls back to without it."""
     script = tmp_path / "group_frames.py"
     script.write_text(SCRIPT)
-    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=280)
+    env = dict(os.environ, RTK_GROUP_EXCHANGE=setting)
+    r = subprocess.run([sys.executable, str(script), ROOT, exchange], capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0 and "GROUP_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
 
 
@@ -109,8 +116,19 @@ def test_group_argument_errors(rtk):
     assert lib.rtk_group_render_device(g, C.byref(cam), None, None, None) == rtk.abi.RTK_ERR_INVALID  # no scene yet
     assert b"rtk_group_upload" in lib.rtk_last_error()
     assert lib.rtk_group_size(g) == 1 and lib.rtk_group_size(None) == 0
-    assert lib.rtk_group_band_tile_rows(g, 2160) == 8 and lib.rtk_group_band_tile_rows(g, 100) == 1
+    assert lib.rtk_group_exchange(g) == b"none" and lib.rtk_group_exchange(None) == b"none"
+    assert lib.rtk_group_band_tile_rows(g, 2160) == 67 and lib.rtk_group_band_tile_rows(g, 8) == 1
+    assert lib.rtk_group_set_bands_per_member(g, 32) == 0 and lib.rtk_group_band_tile_rows(g, 2160) == 8
+    assert lib.rtk_group_set_bands_per_member(g, 1 << 20) == rtk.abi.RTK_ERR_INVALID
+    assert lib.rtk_group_set_bands_per_member(g, 0) == 0 and lib.rtk_group_band_tile_rows(g, 2160) == 67
+    assert lib.rtk_group_set_bands_per_member(None, 4) == rtk.abi.RTK_ERR_INVALID
     st = rtk.abi.rtk_stats()
     assert lib.rtk_group_get_stats(g, C.byref(st)) == 0 and st.rays_primary == 0
     lib.rtk_group_destroy(g)
     lib.rtk_group_destroy(None)
+    os.environ["RTK_GROUP_EXCHANGE"] = "carrier pigeon"
+    try:
+        two = (C.c_int * 2)(0, 0)
+        assert lib.rtk_group_create(two, 2, C.byref(g)) == rtk.abi.RTK_ERR_INVALID and b"RTK_GROUP_EXCHANGE" in lib.rtk_last_error()
+    finally:
+        del os.environ["RTK_GROUP_EXCHANGE"]

@@ -37,7 +37,7 @@ for name, worlds in (("C4", (1, 2, 4, 8)), ("C5", (1, 8))):
         f_rgba = torch.empty((h, w, 4), dtype=torch.uint8, device=dev.tdev)
     for world in worlds:
         tiles_y = (h + 7) // 8
-        m = max(1, tiles_y // (world * 32))
+        m = max(1, tiles_y // (world * 4))
         worst_band = worst_tile = 0.0
         for rank in range(world):
             tb = timed(lambda: dev.render_device_bands(handle, camera, rank, world, m, out_rgb=f_rgb, out_rgba8=f_rgba), 4)

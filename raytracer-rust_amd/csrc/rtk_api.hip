@@ -337,42 +337,42 @@ void rtk_scene_release(rtk_context* ctx, rtk_scene_handle* h) {
   delete h;
 }
 
+// A sphere on its way into sweep order: the bounding ball of its image and its object index.
+struct SphereKey {
+  double c[3];
+  double r;
+  uint32_t object;
+};
+
 // Reorders the spheres so that every aligned run of kBundle is spatially compact: recursive
 // split along the longest axis of the centres' bounding box, the left part a multiple of
-// kBundle.  Deterministic (ties by original position).
-static void cluster_order(std::vector<double4>& exact, std::vector<uint32_t>& object) {
-  const uint32_t n = (uint32_t)exact.size();
-  if (n <= rtk::kBundle) return;
-  std::vector<uint32_t> idx(n);
-  for (uint32_t i = 0; i < n; ++i) idx[i] = i;
-  std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, n}};
-  while (!todo.empty()) {
-    const auto [lo, hi] = todo.back();
-    todo.pop_back();
-    if (hi - lo <= (uint32_t)rtk::kBundle) continue;
+// kBundle.  Which spheres end up in which run does not depend on how the work is scheduled (ties
+// by object index); the two halves of a large range are split on two threads.
+static void cluster_split(SphereKey* keys, uint32_t lo, uint32_t hi, int depth) {
+  while (hi - lo > (uint32_t)rtk::kBundle) {
     double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-    for (uint32_t i = lo; i < hi; ++i) {
-      const double c[3] = {exact[idx[i]].x, exact[idx[i]].y, exact[idx[i]].z};
-      for (int a = 0; a < 3; ++a) mn[a] = std::fmin(mn[a], c[a]), mx[a] = std::fmax(mx[a], c[a]);
-    }
+    for (uint32_t i = lo; i < hi; ++i)
+      for (int a = 0; a < 3; ++a) mn[a] = std::fmin(mn[a], keys[i].c[a]), mx[a] = std::fmax(mx[a], keys[i].c[a]);
     int axis = 0;
     for (int a = 1; a < 3; ++a)
       if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
     const uint32_t groups = (hi - lo + rtk::kBundle - 1) / rtk::kBundle;
     const uint32_t mid = lo + (groups / 2) * rtk::kBundle;
-    auto key = [&](uint32_t i) { return axis == 0 ? exact[i].x : axis == 1 ? exact[i].y : exact[i].z; };
-    std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, [&](uint32_t p, uint32_t q) {
-      const double kp = key(p), kq = key(q);
-      return kp < kq || (kp == kq && p < q);
+    std::nth_element(keys + lo, keys + mid, keys + hi, [axis](const SphereKey& p, const SphereKey& q) {
+      return p.c[axis] < q.c[axis] || (p.c[axis] == q.c[axis] && p.object < q.object);
     });
-    todo.push_back({lo, mid});
-    todo.push_back({mid, hi});
+    if (depth < 3 && hi - lo >= 2048u) {
+      try {
+        std::thread left(cluster_split, keys, lo, mid, depth + 1);
+        cluster_split(keys, mid, hi, depth + 1);
+        left.join();
+        return;
+      } catch (const std::system_error&) {  // no thread to be had: both halves here
+      }
+    }
+    cluster_split(keys, lo, mid, depth + 1);
+    lo = mid;
   }
-  std::vector<double4> e2(n);
-  std::vector<uint32_t> o2(n);
-  for (uint32_t i = 0; i < n; ++i) e2[i] = exact[idx[i]], o2[i] = object[idx[i]];
-  exact.swap(e2);
-  object.swap(o2);
 }
 
 static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& out);
@@ -444,11 +444,10 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   }
   if (!flat.staged) return fail(RTK_ERR_NOMEM, "rtk_scene_upload: no staging memory");
   DevObject* const objects = reinterpret_cast<DevObject*>(flat.staged);
-  std::vector<DevLight> lights(scene->n_lights);
-  std::vector<uint32_t> sph_object, plane_object;
-  std::vector<double4> sph_exact;
+  std::vector<uint32_t> plane_object;
   std::vector<double> pattern_inv;  // stays empty unless some pattern has a transform of its own
   bool track_n1 = false, any_secondary = false;
+  float r2_max = 0.f, r_max = 0.f, c_max = 0.f;
 
   // Per-object work (validation, the reference's cofactor inverse, bounding ball) is independent:
   // large scenes split it over a few host threads.  Errors are reported for the lowest object index.
@@ -534,101 +533,30 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
     track_n1 = track_n1 || oc.track_n1;
     any_secondary = any_secondary || oc.any_secondary;
   }
-  sph_object.reserve(n_padded);
-  sph_exact.reserve(n_all);
+  // spheres (with the bounding balls of their images) and planes, in object order
+  std::vector<SphereKey> keys;
+  keys.reserve(n_all);
   for (uint32_t i = 0; i < scene->n_objects; ++i) {
-    if (objects[i].kind == RTK_PLANE) {
+    if (objects[i].kind == RTK_PLANE)
       plane_object.push_back(i);
-    } else {
-      sph_object.push_back(i);
-      sph_exact.push_back(ball[i]);
-    }
+    else
+      keys.push_back({{ball[i].x, ball[i].y, ball[i].z}, ball[i].w, i});
   }
-  for (uint32_t k = 0; k < scene->n_lights; ++k) {
-    std::memcpy(lights[k].pos, scene->lights[k].position, sizeof lights[k].pos);
-    std::memcpy(lights[k].intensity, scene->lights[k].intensity, sizeof lights[k].intensity);
-    lights[k].reserved_ = 0.0;
-  }
-
   // Sweep order of the spheres: spatial clusters of kBundle (a k-d split down to kBundle
   // members), so that the wavefront-level tests can skip whole clusters.  Closest-hit ties
   // are decided by object index (closest_consider), not by sweep order.
-  const uint32_t n_sph = (uint32_t)sph_exact.size();
-  cluster_order(sph_exact, sph_object);
+  const uint32_t n_sph = (uint32_t)keys.size();
+  cluster_split(keys.data(), 0u, n_sph, 0);
 
-  // FP32 filter records, recentred on the middle of the sphere centres' bounding box
+  // the FP32 records are recentred on the middle of the sphere centres' bounding box
   const uint32_t n_pad = round_up_to(n_sph, kBundle);
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-  for (uint32_t i = 0; i < n_sph; ++i) {
-    const double c[3] = {sph_exact[i].x, sph_exact[i].y, sph_exact[i].z};
+  for (uint32_t i = 0; i < n_sph; ++i)
     for (int a = 0; a < 3; ++a) {
-      if (i == 0 || c[a] < lo[a]) lo[a] = c[a];
-      if (i == 0 || c[a] > hi[a]) hi[a] = c[a];
+      if (i == 0 || keys[i].c[a] < lo[a]) lo[a] = keys[i].c[a];
+      if (i == 0 || keys[i].c[a] > hi[a]) hi[a] = keys[i].c[a];
     }
-  }
-  double center[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
-  std::vector<float4> filter(n_pad);
-  float r2_max = 0.f, r_max = 0.f, c_max = 0.f;
-  for (uint32_t i = 0; i < n_pad; ++i) {
-    if (i >= n_sph) {
-      // padding repeats the last real record (and its object index): a repeated candidate is
-      // re-evaluated to the same roots, which changes no closest-hit or shadow decision
-      filter[i] = filter[n_sph - 1];
-      sph_object.push_back(sph_object[n_sph - 1]);
-      continue;
-    }
-    const double c[3] = {sph_exact[i].x - center[0], sph_exact[i].y - center[1], sph_exact[i].z - center[2]};
-    const float cf[3] = {(float)c[0], (float)c[1], (float)c[2]};
-    const double dx = c[0] - cf[0], dy = c[1] - cf[1], dz = c[2] - cf[2];
-    const double shift = std::sqrt(dx * dx + dy * dy + dz * dz);  // actual displacement of the rounded centre
-    const double R = sph_exact[i].w * (1.0 + 1e-9) + shift * 1.0001;
-    const float r2 = round_up(R * R);
-    filter[i] = make_float4(cf[0], cf[1], cf[2], r2);
-    r2_max = std::fmax(r2_max, r2);
-    r_max = std::fmax(r_max, round_up(R));
-    c_max = std::fmax(c_max, round_up(std::sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]) * 1.0001));
-  }
-
-  // exact-test records in sweep order (padding repeats the last real one, like the filter records)
-  std::vector<SphRecord> sph_record(n_pad);
-  for (uint32_t j = 0; j < n_pad; ++j) {
-    const uint32_t obj = sph_object[j];
-    const double* m = objects[obj].inv;
-    SphRecord& r = sph_record[j];
-    r.scale[0] = m[0], r.scale[1] = m[5], r.scale[2] = m[10];
-    r.shift[0] = m[3], r.shift[1] = m[7], r.shift[2] = m[11];
-    r.object = obj;
-    r.diagonal = (m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[8] == 0.0 && m[9] == 0.0) ? 1u : 0u;
-    r.reserved_ = 0;
-  }
-
-  // records of the wavefront-level test: centre and (not squared) inflated radius
-  std::vector<float4> sph_ball(n_pad);
-  for (uint32_t j = 0; j < n_pad; ++j) {
-    if (j >= n_sph) {
-      sph_ball[j] = make_float4(0.f, 0.f, 0.f, -1.0e30f);
-      continue;
-    }
-    const float4 f = filter[j];
-    sph_ball[j] = make_float4(f.x, f.y, f.z, round_up(std::sqrt((double)f.w) * (1.0 + 1e-7)));
-  }
-
-  // one ball per cluster of kBundle spheres, around the balls of its members
-  const uint32_t n_clusters = n_pad / kBundle, n_clusters_pad = round_up_to(n_clusters, kBundle);
-  std::vector<float4> cluster_ball(n_clusters_pad, make_float4(0.f, 0.f, 0.f, -1.0e30f));
-  for (uint32_t c = 0; c < n_clusters; ++c) {
-    double m[3] = {0, 0, 0};
-    uint32_t members = 0;
-    for (uint32_t j = c * kBundle; j < std::min((c + 1) * (uint32_t)kBundle, n_sph); ++j, ++members)
-      m[0] += sph_ball[j].x, m[1] += sph_ball[j].y, m[2] += sph_ball[j].z;
-    const float mf[3] = {(float)(m[0] / members), (float)(m[1] / members), (float)(m[2] / members)};
-    double reach = 0.0;
-    for (uint32_t j = c * kBundle; j < c * kBundle + members; ++j) {
-      const double dx = (double)sph_ball[j].x - mf[0], dy = (double)sph_ball[j].y - mf[1], dz = (double)sph_ball[j].z - mf[2];
-      reach = std::fmax(reach, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)sph_ball[j].w);
-    }
-    cluster_ball[c] = make_float4(mf[0], mf[1], mf[2], round_up(reach * (1.0 + 1e-7)));
-  }
+  const double center[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
 
   // Lights with w == 0 (what scene files produce, src/loader.rs:35-40): the shadow-ray line
   // direction G = L.xyz does not depend on the shading point, so the per-(sphere, light)
@@ -637,94 +565,192 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   // the bundle of a patch is a cone with its apex at the light.  Their record is the light's
   // position, recentred like the sphere records.  lights_bundled: every light is one or the other.
   bool lights_uniform = scene->n_lights > 0, lights_bundled = scene->n_lights > 0;
-  std::vector<float4> light_filter(scene->n_lights);
-  std::vector<uint32_t> light_kind(scene->n_lights, 2u);  // 0: w == 0, 1: w == 1, 2: anything else
   std::vector<double> gd(4 * (size_t)scene->n_lights);
   for (uint32_t k = 0; k < scene->n_lights; ++k) {
     const double* L = scene->lights[k].position;
     const double gg = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
     if (L[3] == 1.0 && std::isfinite(gg)) {
       lights_uniform = false;
-      light_kind[k] = 1u;
-      light_filter[k] = make_float4((float)(L[0] - center[0]), (float)(L[1] - center[1]), (float)(L[2] - center[2]), 0.f);
       continue;
     }
     if (L[3] != 0.0 || !(gg > 0.0) || !std::isfinite(gg)) {
       lights_uniform = false;
       lights_bundled = false;
-      light_filter[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       continue;
     }
-    light_kind[k] = 0u;
     const double inv = 1.0 / std::sqrt(gg);
     gd[4 * k + 0] = L[0] * inv;
     gd[4 * k + 1] = L[1] * inv;
     gd[4 * k + 2] = L[2] * inv;
     gd[4 * k + 3] = -inv;  // rho = (w - 1)/|G|
-    light_filter[k] = make_float4((float)gd[4 * k], (float)gd[4 * k + 1], (float)gd[4 * k + 2], (float)gd[4 * k + 3]);
   }
   const uint32_t k_width = 4u;  // lights per table row and per sweep batch
-  std::vector<float> k_table;
-  std::vector<float4> sph_tab;
-  if (lights_uniform && n_pad) {
-    sph_tab.resize(n_pad);
-    const double kappa = (double)(1.0f - 24.0f * rtk::kEps32);
-    for (uint32_t j = 0; j < n_pad; ++j) {
-      const float4 f = filter[j];
-      const double cc = kappa * ((double)f.x * f.x + (double)f.y * f.y + (double)f.z * f.z) - (double)f.w;
-      float ccf = (float)cc;
-      if ((double)ccf > cc) ccf = std::nextafterf(ccf, -INFINITY);
-      sph_tab[j] = make_float4(f.x, f.y, f.z, std::nextafterf(ccf, -INFINITY));
-    }
-    const uint32_t batches = (scene->n_lights + k_width - 1) / k_width;
-    k_table.resize((size_t)batches * n_pad * k_width);
-    for (uint32_t b = 0; b < batches; ++b)
-      for (uint32_t j = 0; j < n_pad; ++j)
-        for (uint32_t e = 0; e < k_width; ++e) {
-          const uint32_t k = std::min(b * k_width + e, scene->n_lights - 1);  // pad a short batch with its last light
-          const float4 f = filter[j];
-          const double v = (double)f.x * gd[4 * k] + (double)f.y * gd[4 * k + 1] + (double)f.z * gd[4 * k + 2] -
-                           (double)f.w * gd[4 * k + 3];
-          k_table[((size_t)b * n_pad + j) * k_width + e] = (float)v;
-        }
-  }
+  const bool tabulated = lights_uniform && n_pad;
+  const uint32_t batches = (scene->n_lights + k_width - 1) / k_width;
 
-  // One device allocation and one copy for all record arrays (each 256-byte aligned inside it);
-  // the per-camera records, which only kernels write, follow at its end.
-  struct Source {
-    const void* src;
-    size_t bytes, offset;
-  };
-  std::vector<Source> sources;
+  // One device allocation and one copy for all record arrays (each 256-byte aligned inside it):
+  // the arrays are laid out first and then written where they will be copied from.  The
+  // per-camera records, which only kernels write, follow at the end of the allocation.
+  const uint32_t n_clusters = n_pad / kBundle, n_clusters_pad = round_up_to(n_clusters, kBundle);
   size_t total = 0;
-  auto place = [&](void* rtk_scene_handle::*dst, const void* src, size_t bytes) {
-    if (bytes == 0) return;
+  auto reserve = [&](void* rtk_scene_handle::*dst, size_t bytes) -> size_t {
+    const size_t at = total;
+    if (bytes == 0) return at;
     flat.pieces.push_back({dst, bytes, total});
-    if (src) sources.push_back({src, bytes, total});
     total += (bytes + 255u) & ~(size_t)255u;
+    return at;
   };
-  place(&rtk_scene_handle::d_objects, nullptr, (size_t)scene->n_objects * sizeof(DevObject));  // already in place
-  place(&rtk_scene_handle::d_lights, lights.data(), lights.size() * sizeof(DevLight));
-  place(&rtk_scene_handle::d_filter, filter.data(), filter.size() * sizeof(float4));
-  place(&rtk_scene_handle::d_exact, sph_exact.data(), sph_exact.size() * sizeof(double4));
-  place(&rtk_scene_handle::d_sph_object, sph_object.data(), sph_object.size() * sizeof(uint32_t));
-  place(&rtk_scene_handle::d_sph_record, sph_record.data(), sph_record.size() * sizeof(SphRecord));
-  place(&rtk_scene_handle::d_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
-  place(&rtk_scene_handle::d_pattern_inv, pattern_inv.data(), pattern_inv.size() * sizeof(double));
-  place(&rtk_scene_handle::d_light_filter, light_filter.data(), light_filter.size() * sizeof(float4));
-  place(&rtk_scene_handle::d_light_kind, light_kind.data(), light_kind.size() * sizeof(uint32_t));
-  place(&rtk_scene_handle::d_k_table, k_table.data(), k_table.size() * sizeof(float));
-  place(&rtk_scene_handle::d_sph_tab, sph_tab.data(), sph_tab.size() * sizeof(float4));
-  place(&rtk_scene_handle::d_sph_ball, sph_ball.data(), sph_ball.size() * sizeof(float4));
-  place(&rtk_scene_handle::d_cluster_ball, cluster_ball.data(), cluster_ball.size() * sizeof(float4));
+  const size_t at_objects = reserve(&rtk_scene_handle::d_objects, (size_t)scene->n_objects * sizeof(DevObject));  // already in place
+  const size_t at_lights = reserve(&rtk_scene_handle::d_lights, (size_t)scene->n_lights * sizeof(DevLight));
+  const size_t at_filter = reserve(&rtk_scene_handle::d_filter, (size_t)n_pad * sizeof(float4));
+  const size_t at_exact = reserve(&rtk_scene_handle::d_exact, (size_t)n_sph * sizeof(double4));
+  const size_t at_sph_object = reserve(&rtk_scene_handle::d_sph_object, (size_t)n_pad * sizeof(uint32_t));
+  const size_t at_sph_record = reserve(&rtk_scene_handle::d_sph_record, (size_t)n_pad * sizeof(SphRecord));
+  const size_t at_plane_object = reserve(&rtk_scene_handle::d_plane_object, plane_object.size() * sizeof(uint32_t));
+  const size_t at_pattern_inv = reserve(&rtk_scene_handle::d_pattern_inv, pattern_inv.size() * sizeof(double));
+  const size_t at_light_filter = reserve(&rtk_scene_handle::d_light_filter, (size_t)scene->n_lights * sizeof(float4));
+  const size_t at_light_kind = reserve(&rtk_scene_handle::d_light_kind, (size_t)scene->n_lights * sizeof(uint32_t));
+  const size_t at_k_table = reserve(&rtk_scene_handle::d_k_table, tabulated ? (size_t)batches * n_pad * k_width * sizeof(float) : 0);
+  const size_t at_sph_tab = reserve(&rtk_scene_handle::d_sph_tab, tabulated ? (size_t)n_pad * sizeof(float4) : 0);
+  const size_t at_sph_ball = reserve(&rtk_scene_handle::d_sph_ball, (size_t)n_pad * sizeof(float4));
+  const size_t at_cluster_ball = reserve(&rtk_scene_handle::d_cluster_ball, n_pad ? (size_t)n_clusters_pad * sizeof(float4) : 0);
   const size_t copied = total;
-  place(&rtk_scene_handle::d_prim, nullptr, n_pad * sizeof(float4));
-  place(&rtk_scene_handle::d_prim_ball, nullptr, n_pad * sizeof(float4));
-  place(&rtk_scene_handle::d_prim_cluster, nullptr, n_pad ? n_clusters_pad * sizeof(float4) : 0);
+  reserve(&rtk_scene_handle::d_prim, (size_t)n_pad * sizeof(float4));
+  reserve(&rtk_scene_handle::d_prim_ball, (size_t)n_pad * sizeof(float4));
+  reserve(&rtk_scene_handle::d_prim_cluster, n_pad ? (size_t)n_clusters_pad * sizeof(float4) : 0);
   flat.total = total;
   flat.staged_bytes = copied;
-  if (copied > bound) return fail(RTK_ERR_INVALID, "rtk_scene_upload: staging bound exceeded");  // cannot happen
-  for (const Source& p : sources) std::memcpy(flat.staged + p.offset, p.src, p.bytes);
+  if (at_objects != 0 || copied > bound) return fail(RTK_ERR_INVALID, "rtk_scene_upload: staging bound exceeded");  // cannot happen
+  unsigned char* const base = flat.staged;
+  DevLight* const lights = reinterpret_cast<DevLight*>(base + at_lights);
+  float4* const filter = reinterpret_cast<float4*>(base + at_filter);
+  double4* const sph_exact = reinterpret_cast<double4*>(base + at_exact);
+  uint32_t* const sph_object = reinterpret_cast<uint32_t*>(base + at_sph_object);
+  SphRecord* const sph_record = reinterpret_cast<SphRecord*>(base + at_sph_record);
+  float4* const light_filter = reinterpret_cast<float4*>(base + at_light_filter);
+  uint32_t* const light_kind = reinterpret_cast<uint32_t*>(base + at_light_kind);
+  float* const k_table = reinterpret_cast<float*>(base + at_k_table);
+  float4* const sph_tab = reinterpret_cast<float4*>(base + at_sph_tab);
+  float4* const sph_ball = reinterpret_cast<float4*>(base + at_sph_ball);
+  float4* const cluster_ball = reinterpret_cast<float4*>(base + at_cluster_ball);
+  if (!plane_object.empty()) std::memcpy(base + at_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
+  if (!pattern_inv.empty()) std::memcpy(base + at_pattern_inv, pattern_inv.data(), pattern_inv.size() * sizeof(double));
+
+  for (uint32_t k = 0; k < scene->n_lights; ++k) {
+    std::memcpy(lights[k].pos, scene->lights[k].position, sizeof lights[k].pos);
+    std::memcpy(lights[k].intensity, scene->lights[k].intensity, sizeof lights[k].intensity);
+    lights[k].reserved_ = 0.0;
+    const double* L = scene->lights[k].position;
+    const double gg = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
+    if (L[3] == 1.0 && std::isfinite(gg)) {
+      light_kind[k] = 1u;
+      light_filter[k] = make_float4((float)(L[0] - center[0]), (float)(L[1] - center[1]), (float)(L[2] - center[2]), 0.f);
+    } else if (L[3] != 0.0 || !(gg > 0.0) || !std::isfinite(gg)) {
+      light_kind[k] = 2u;
+      light_filter[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      light_kind[k] = 0u;
+      light_filter[k] = make_float4((float)gd[4 * k], (float)gd[4 * k + 1], (float)gd[4 * k + 2], (float)gd[4 * k + 3]);
+    }
+  }
+
+  // Every record of a sphere follows from its key alone, so the clusters are shared out among a few
+  // host threads; each keeps the maxima the kernels' error bounds need.
+  struct Maxima {
+    float r2 = 0.f, r = 0.f, c = 0.f;
+  };
+  const double kappa = (double)(1.0f - 24.0f * rtk::kEps32);
+  auto tabulate = [&](uint32_t j) {  // the per-(sphere, light) tables of sphere slot j, from its filter record
+    const float4 f = filter[j];
+    const double cc = kappa * ((double)f.x * f.x + (double)f.y * f.y + (double)f.z * f.z) - (double)f.w;
+    float ccf = (float)cc;
+    if ((double)ccf > cc) ccf = std::nextafterf(ccf, -INFINITY);
+    sph_tab[j] = make_float4(f.x, f.y, f.z, std::nextafterf(ccf, -INFINITY));
+    for (uint32_t b = 0; b < batches; ++b)
+      for (uint32_t e = 0; e < k_width; ++e) {
+        const uint32_t k = std::min(b * k_width + e, scene->n_lights - 1);  // pad a short batch with its last light
+        const double v = (double)f.x * gd[4 * k] + (double)f.y * gd[4 * k + 1] + (double)f.z * gd[4 * k + 2] - (double)f.w * gd[4 * k + 3];
+        k_table[((size_t)b * n_pad + j) * k_width + e] = (float)v;
+      }
+  };
+  auto exact_record = [&](uint32_t j, uint32_t obj) {  // exact-test record of sweep slot j
+    const double* m = objects[obj].inv;
+    SphRecord& r = sph_record[j];
+    r.scale[0] = m[0], r.scale[1] = m[5], r.scale[2] = m[10];
+    r.shift[0] = m[3], r.shift[1] = m[7], r.shift[2] = m[11];
+    r.object = obj;
+    r.diagonal = (m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[8] == 0.0 && m[9] == 0.0) ? 1u : 0u;
+    r.reserved_ = 0;
+  };
+  auto cluster_records = [&](uint32_t c_begin, uint32_t c_end, Maxima& mx) {
+    for (uint32_t c = c_begin; c < c_end; ++c) {
+      const uint32_t j0 = c * kBundle, members = std::min<uint32_t>(kBundle, n_sph - j0);
+      for (uint32_t j = j0; j < j0 + members; ++j) {
+        const SphereKey& key = keys[j];
+        sph_exact[j] = make_double4(key.c[0], key.c[1], key.c[2], key.r);
+        sph_object[j] = key.object;
+        // FP32 filter record: the rounded centre, and a radius that covers the rounding
+        const double cd[3] = {key.c[0] - center[0], key.c[1] - center[1], key.c[2] - center[2]};
+        const float cf[3] = {(float)cd[0], (float)cd[1], (float)cd[2]};
+        const double dx = cd[0] - cf[0], dy = cd[1] - cf[1], dz = cd[2] - cf[2];
+        const double shift = std::sqrt(dx * dx + dy * dy + dz * dz);  // actual displacement of the rounded centre
+        const double R = key.r * (1.0 + 1e-9) + shift * 1.0001;
+        const float r2 = round_up(R * R);
+        filter[j] = make_float4(cf[0], cf[1], cf[2], r2);
+        mx.r2 = std::fmax(mx.r2, r2);
+        mx.r = std::fmax(mx.r, round_up(R));
+        mx.c = std::fmax(mx.c, round_up(std::sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]) * 1.0001));
+        exact_record(j, key.object);
+        // record of the wavefront-level test: centre and (not squared) inflated radius
+        sph_ball[j] = make_float4(cf[0], cf[1], cf[2], round_up(std::sqrt((double)r2) * (1.0 + 1e-7)));
+        if (tabulated) tabulate(j);
+      }
+      // Slots behind the last sphere repeat its records (and its object index): a repeated candidate
+      // is re-evaluated to the same roots, which changes no closest-hit or shadow decision.  Their
+      // wavefront-level ball is empty.
+      for (uint32_t j = j0 + members; j < j0 + kBundle; ++j) {
+        filter[j] = filter[n_sph - 1];
+        sph_object[j] = sph_object[n_sph - 1];
+        exact_record(j, sph_object[j]);
+        sph_ball[j] = make_float4(0.f, 0.f, 0.f, -1.0e30f);
+        if (tabulated) tabulate(j);
+      }
+      // one ball per cluster, around the balls of its members
+      double m[3] = {0, 0, 0};
+      for (uint32_t j = j0; j < j0 + members; ++j) m[0] += sph_ball[j].x, m[1] += sph_ball[j].y, m[2] += sph_ball[j].z;
+      const float mf[3] = {(float)(m[0] / members), (float)(m[1] / members), (float)(m[2] / members)};
+      double reach = 0.0;
+      for (uint32_t j = j0; j < j0 + members; ++j) {
+        const double dx = (double)sph_ball[j].x - mf[0], dy = (double)sph_ball[j].y - mf[1], dz = (double)sph_ball[j].z - mf[2];
+        reach = std::fmax(reach, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)sph_ball[j].w);
+      }
+      cluster_ball[c] = make_float4(mf[0], mf[1], mf[2], round_up(reach * (1.0 + 1e-7)));
+    }
+  };
+  for (uint32_t c = n_clusters; c < n_clusters_pad; ++c) cluster_ball[c] = make_float4(0.f, 0.f, 0.f, -1.0e30f);
+  {
+    const uint32_t workers = n_clusters < 32u ? 1u : std::max(1u, std::min({8u, hw ? hw : 1u, n_clusters / 16u}));
+    std::vector<Maxima> maxima(workers);
+    std::vector<std::thread> pool;
+    pool.reserve(workers);
+    const uint32_t chunk = (n_clusters + workers - 1) / workers;
+    // the last cluster (the only one that may have empty slots, which read the last sphere's records) runs
+    // here, after the others
+    const uint32_t n_parallel = n_clusters ? n_clusters - 1 : 0;
+    for (uint32_t t = 1; t < workers; ++t) {
+      const uint32_t begin = std::min(t * chunk, n_parallel), end_ = std::min((t + 1) * chunk, n_parallel);
+      if (begin == end_) continue;
+      try {
+        pool.emplace_back(cluster_records, begin, end_, std::ref(maxima[t]));
+      } catch (...) {  // no thread to be had: this chunk runs here
+        cluster_records(begin, end_, maxima[t]);
+      }
+    }
+    cluster_records(0, std::min(chunk, n_parallel), maxima[0]);
+    for (std::thread& t : pool) t.join();
+    if (n_clusters) cluster_records(n_clusters - 1, n_clusters, maxima[0]);
+    for (const Maxima& mx : maxima) r2_max = std::fmax(r2_max, mx.r2), r_max = std::fmax(r_max, mx.r), c_max = std::fmax(c_max, mx.c);
+  }
 
   DevScene& d = flat.dev;
   d = DevScene{};

@@ -160,17 +160,20 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
         if (cand != 0ull) {
           const uint32_t b = (uint32_t)__builtin_ctzll(cand);
           cand &= cand - 1ull;
-          const float4 c = S.sph_filter[first + b];
-          const float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
-          const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-          const float cf = __builtin_fmaf(uu, kKappa, -c.w);
-          uint32_t mask = 0;
+          uint32_t mask = 1u;  // one ray per lane: the sphere passed that ray's test above
+          if (NR > 1) {        // several: which of them
+            const float4 c = S.sph_filter[first + b];
+            const float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
+            const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+            const float cf = __builtin_fmaf(uu, kKappa, -c.w);
+            mask = 0;
 #pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            const float h = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], __builtin_fmaf(ux, gx[r], c.w * rho[r])));
-            if (__builtin_fmaf(h, h, -cf) >= thr) mask |= 1u << r;
+            for (int r = 0; r < NR; ++r) {
+              const float h = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], __builtin_fmaf(ux, gx[r], c.w * rho[r])));
+              if (__builtin_fmaf(h, h, -cf) >= thr) mask |= 1u << r;
+            }
           }
-          if (mask) exact(S.sph_object[first + b], mask);
+          if (mask) exact(first + b, mask);
           if (active && done()) active = false, cand = 0ull;
         }
       }
@@ -208,10 +211,7 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
             if (__builtin_fmaf(h, h, -cf) >= thr) mask |= 1u << r;
           }
           if (!reach) mask = 0;
-          if (__any(mask != 0)) {
-            uint32_t obj = S.sph_object[j + g];
-            if (mask) exact(obj, mask);
-          }
+          if (mask) exact(j + g, mask);
         }
         // lanes that need no further test drop out; the wavefront stops once all have
         if (active && done()) active = false, reach = false;
@@ -270,8 +270,8 @@ __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3
     V3 pc = {p.x - S.center[0], p.y - S.center[1], p.z - S.center[2]};
     float thr = exotic ? -3.0e38f : filter_threshold(S, pc, rho_max);
     bool live = need && !(occl & 1u);
-    auto exact = [&](uint32_t obj, uint32_t mask) {
-      const RTK_RO DevObject& ob = S.objects[obj];
+    auto exact = [&](uint32_t slot, uint32_t mask) {
+      const RTK_RO SphRecord& rec = S.sph_record[slot];
       for (uint32_t r = 0; r < nb; ++r) {
         if (!((mask >> r) & 1u) || ((occl >> r) & 1u)) continue;
         const RTK_RO DevLight& L = S.lights[kb + r];
@@ -280,7 +280,7 @@ __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3
         double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
         V3 d = {lv.x / m, lv.y / m, lv.z / m};
         double t0, t1;
-        int n = intersect_object(ob, p, d, lw / m, t0, t1);
+        int n = intersect_sphere_record(S, rec, p, d, lw / m, t0, t1);
         ++n_exact;
         if (n == 2 && ((t0 > 0.0 && t0 < m) || (t1 > 0.0 && t1 < m))) occl |= 1u << r;
       }
@@ -322,10 +322,12 @@ __device__ __forceinline__ void closest_general(const DevScene& S, bool active, 
   make_filter_ray(d, 0.0, gx[0], gy[0], gz[0], rho[0]);
   V3 pc = {o.x - S.center[0], o.y - S.center[1], o.z - S.center[2]};
   float thr = filter_threshold(S, pc, 0.0f);
-  auto exact = [&](uint32_t obj, uint32_t) {
+  auto exact = [&](uint32_t slot, uint32_t) {
+    const RTK_RO SphRecord& rec = S.sph_record[slot];
+    const uint32_t obj = rec.object;
     double t0, t1;
     ++n_exact;
-    if (intersect_object(S.objects[obj], o, d, 0.0, t0, t1)) {
+    if (intersect_sphere_record(S, rec, o, d, 0.0, t0, t1)) {
       closest_consider(best, t0, obj, track);
       closest_consider(best, t1, obj, track);
       if (track && fabs(t0 - t1) < 0.00001) graze = true;  // `Hit::eq` would call the two roots one hit

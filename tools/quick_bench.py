@@ -9,13 +9,17 @@ if os.environ.get("RTK_LIB"):  # A/B runs: another build of the library
 dev = device.Device(0)
 names = sys.argv[1:] or ["C2", "C3", "C4"]
 for name in names:
+    size = (1920, 1080)
+    if "@" in name:  # e.g. C4g@3840x2160
+        name, res = name.split("@")
+        size = tuple(int(v) for v in res.split("x"))
     if name == "C1":
         scene = rtk.PackedScene.from_yaml_file(os.path.join(ROOT, "tests/golden/test01.yaml")).build()
         camera = rtk.Camera(1920, 1080, rtk.PI / 3)
     elif name in ("C3g", "C4g"):  # the glass variant of a big configuration at 1080p: secondary rays
         n = 1000 if name == "C3g" else 10000
         scene = rtk.synthetic.make_scene(n, True, 4, 0xC0FFEE00 + n, glass=True)
-        camera = rtk.synthetic.make_camera(n, 1920, 1080)
+        camera = rtk.synthetic.make_camera(n, *size)
     elif name == "C3w1":           # C3 with w = 1 lights: the two-kernel opaque path
         scene, camera = rtk.synthetic.config("C3")
         scene.lights = [rtk.PointLight(rtk.point(*l.position[:3]), l.intensity) for l in scene.lights]
@@ -53,5 +57,5 @@ for name in names:
     nsph = sum(1 for n in scene.nodes if n.kind == 0)
     fl = 26 * nsph + 8 * (len(scene.nodes) - nsph)
     print(f"{name}: {best.kernel_ms:8.3f} ms  {best.rays / best.kernel_ms / 1e3:9.1f} Mrays/s  "
-          f"{100 * best.rays * fl / (best.kernel_ms * 1e-3) / 157.3e12:6.1f}% of FP32 peak (algorithmic)  exact/ray-test {best.exact_tests / (best.rays * max(nsph,1)):.2e}", flush=True)
+          f"{100 * best.rays * fl / (best.kernel_ms * 1e-3) / 157.3e12:6.1f}% of FP32 peak (algorithmic)  exact/ray-test {best.exact_tests / (best.rays * max(nsph,1)):.2e}  rays {best.rays_primary}+{best.rays_secondary}+{best.rays_shadow}", flush=True)
     h.release()

@@ -305,6 +305,25 @@ int rtk_untile_strided(rtk_context* ctx, uint32_t width, uint32_t height, uint32
                        const float* d_rgb_f32_compact, float* d_rgb_f32_frame,
                        const uint8_t* d_rgba8_compact, uint8_t* d_rgba8_frame, void* hip_stream);
 
+/* How scenes with reflective or transparent materials are traced.  No counterpart in the reference
+ * (`Scene::trace` recurses, src/scene.rs:136-296); the frame is the same bit for bit either way.
+ *   RTK_TRACE_DEPTH_FIRST: one lane walks a pixel's whole ray tree; needs no memory beyond the frame.
+ *   RTK_TRACE_BY_LEVEL:    the nodes of all pixels are traced one tree level per launch from a queue in
+ *                          device memory (128 bytes per node), the pixels are summed from the node
+ *                          records afterwards in depth-first order.  No pixel holds a wavefront up, so
+ *                          small and medium launches finish much sooner; large ones pay for the queue.
+ *   RTK_TRACE_AUTO:        (default) by level where that is expected to be faster: scenes of 256
+ *                          spheres and more, launches up to a few million pixels.
+ * max_queue_nodes: capacity of the queue (0 keeps the current one; the default is 64 Mi nodes = 8 GB,
+ * or the environment variable RTK_WAVEFRONT_NODES read by rtk_create, where 0 turns tracing by level
+ * off).  The queue is allocated on first use at 6 nodes per pixel of the launch, up to the capacity;
+ * launches that need more run in passes, and a pass whose nodes still do not fit is traced again
+ * depth first.  Waits for the context's frames in flight when the capacity changes. */
+#define RTK_TRACE_AUTO 0u
+#define RTK_TRACE_DEPTH_FIRST 1u
+#define RTK_TRACE_BY_LEVEL 2u
+int rtk_set_trace_order(rtk_context* ctx, uint32_t order, uint64_t max_queue_nodes);
+
 /* Waits for the stream of the last render and returns its ray counts and kernel time. */
 int rtk_get_stats(rtk_context* ctx, rtk_stats* stats);
 

@@ -28,6 +28,9 @@ RTK_MAX_DEPTH_LIMIT = 8
 RTK_MAX_LIGHTS = 32767
 RTK_TIMING_HISTORY = 64
 RTK_MAX_SAMPLES_PER_AXIS = 16
+RTK_TRACE_AUTO = 0
+RTK_TRACE_DEPTH_FIRST = 1
+RTK_TRACE_BY_LEVEL = 2
 RTK_TILE_W = 32
 RTK_TILE_H = 8
 RTK_STATIC_MAX_SPHERES = 32768
@@ -195,6 +198,7 @@ SYMBOLS = {
     "rtk_group_band_tile_rows": (C.c_uint32, [C.c_void_p, C.c_uint32]),
     "rtk_group_set_bands_per_member": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rtk_group_exchange": (C.c_char_p, [C.c_void_p]),
+    "rtk_set_trace_order": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64]),
     "rtk_last_error": (C.c_char_p, []),
     "rtk_version": (C.c_char_p, []),
 }

@@ -11,6 +11,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -288,6 +289,14 @@ int rtk_create(int device_id, rtk_context** out) {
   rtk_context* ctx = new (std::nothrow) rtk_context();
   if (!ctx) return fail(RTK_ERR_NOMEM, "rtk_create: out of host memory");
   ctx->device = device_id;
+  // Queue room of the level-by-level path: 128 bytes per node, up to 8 GB of the device's 288 unless
+  // RTK_WAVEFRONT_NODES says otherwise (0: scenes with secondary rays stay on the depth-first kernel).
+  ctx->wavefront_max_nodes = 64u << 20;
+  if (const char* v = std::getenv("RTK_WAVEFRONT_NODES")) {
+    char* end = nullptr;
+    const unsigned long long n = std::strtoull(v, &end, 10);
+    if (end != v && *end == '\0') ctx->wavefront_max_nodes = (uint32_t)std::min<unsigned long long>(n, 1ull << 31);
+  }
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = create_timing_events(ctx)) != hipSuccess ||
@@ -298,6 +307,24 @@ int rtk_create(int device_id, rtk_context** out) {
     return fail_hip(e, "rtk_create");
   }
   *out = ctx;
+  return RTK_OK;
+}
+
+int rtk_set_trace_order(rtk_context* ctx, uint32_t order, uint64_t max_queue_nodes) {
+  if (!ctx) return fail(RTK_ERR_INVALID, "rtk_set_trace_order: null context");
+  if (order > RTK_TRACE_BY_LEVEL) return fail(RTK_ERR_INVALID, "rtk_set_trace_order: unknown order");
+  if (max_queue_nodes > (1ull << 31)) return fail(RTK_ERR_INVALID, "rtk_set_trace_order: more than 2^31 queue nodes");
+  ctx->trace_order = order;
+  if (max_queue_nodes) {
+    RTK_HIP(hipSetDevice(ctx->device));
+    RTK_HIP(hipDeviceSynchronize());  // frames in flight may use the queue
+    rtk::WavefrontBuffers& w = ctx->wavefront;
+    if (w.rays) (void)hipFree(w.rays);
+    if (w.outs) (void)hipFree(w.outs);
+    w.rays = nullptr, w.outs = nullptr, w.cap_nodes = 0;
+    w.nodes_per_pixel = rtk::kWavefrontNodesPerPixel;
+    ctx->wavefront_max_nodes = (uint32_t)max_queue_nodes;
+  }
   return RTK_OK;
 }
 
@@ -313,6 +340,11 @@ void rtk_destroy(rtk_context* ctx) {
   if (ctx->opaque.hit_t) (void)hipFree(ctx->opaque.hit_t);
   if (ctx->opaque.shadow) (void)hipFree(ctx->opaque.shadow);
   if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+  if (ctx->wavefront.rays) (void)hipFree(ctx->wavefront.rays);
+  if (ctx->wavefront.outs) (void)hipFree(ctx->wavefront.outs);
+  if (ctx->wavefront.ctrl) (void)hipFree(ctx->wavefront.ctrl);
+  if (ctx->wavefront.counters) (void)hipFree(ctx->wavefront.counters);
+  if (ctx->wavefront.host_overflow) (void)hipHostFree(ctx->wavefront.host_overflow);
   if (ctx->cached_handle) rtk_scene_release(ctx, ctx->cached_handle);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (int i = 0; i < RTK_TIMING_HISTORY; ++i) {
@@ -432,10 +464,10 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   bool any_pattern = false;
   for (uint32_t i = 0; i < scene->n_objects && !any_pattern; ++i) any_pattern = scene->objects[i].material.pattern_transformed != 0;
   const size_t n_all = scene->n_objects, n_padded = n_all + kBundle, n_l = scene->n_lights;
-  const size_t bound = 17 * 256 + n_all * sizeof(DevObject) + n_l * (sizeof(DevLight) + sizeof(float4) + sizeof(uint32_t)) +
+  const size_t bound = 18 * 256 + n_all * sizeof(DevObject) + n_l * (sizeof(DevLight) + sizeof(float4) + sizeof(uint32_t)) +
                        n_padded * (3 * sizeof(float4) + sizeof(uint32_t) + sizeof(SphRecord)) + n_all * (sizeof(double4) + sizeof(uint32_t)) +
                        (any_pattern ? n_all * 12 * sizeof(double) : 0) + ((n_l + 3) / 4) * n_padded * sizeof(float4) +
-                       (n_padded / kBundle + kBundle) * sizeof(float4);
+                       2 * (n_padded / kBundle + kBundle) * sizeof(float4);
   if (flat.grow) {
     flat.staged = flat.grow(flat.user, bound);
   } else {
@@ -614,6 +646,8 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   const size_t at_sph_tab = reserve(&rtk_scene_handle::d_sph_tab, tabulated ? (size_t)n_pad * sizeof(float4) : 0);
   const size_t at_sph_ball = reserve(&rtk_scene_handle::d_sph_ball, (size_t)n_pad * sizeof(float4));
   const size_t at_cluster_ball = reserve(&rtk_scene_handle::d_cluster_ball, n_pad ? (size_t)n_clusters_pad * sizeof(float4) : 0);
+  const uint32_t n_supers = (n_clusters + kSuper - 1) / kSuper;
+  const size_t at_super_ball = reserve(&rtk_scene_handle::d_super_ball, (size_t)n_supers * sizeof(float4));
   const size_t copied = total;
   reserve(&rtk_scene_handle::d_prim, (size_t)n_pad * sizeof(float4));
   reserve(&rtk_scene_handle::d_prim_ball, (size_t)n_pad * sizeof(float4));
@@ -633,6 +667,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   float4* const sph_tab = reinterpret_cast<float4*>(base + at_sph_tab);
   float4* const sph_ball = reinterpret_cast<float4*>(base + at_sph_ball);
   float4* const cluster_ball = reinterpret_cast<float4*>(base + at_cluster_ball);
+  float4* const super_ball = reinterpret_cast<float4*>(base + at_super_ball);
   if (!plane_object.empty()) std::memcpy(base + at_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
   if (!pattern_inv.empty()) std::memcpy(base + at_pattern_inv, pattern_inv.data(), pattern_inv.size() * sizeof(double));
 
@@ -751,6 +786,19 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
     if (n_clusters) cluster_records(n_clusters - 1, n_clusters, maxima[0]);
     for (const Maxima& mx : maxima) r2_max = std::fmax(r2_max, mx.r2), r_max = std::fmax(r_max, mx.r), c_max = std::fmax(c_max, mx.c);
   }
+  // upper level: one ball around the balls of kSuper consecutive clusters (neighbours in the k-d split)
+  for (uint32_t u = 0; u < n_supers; ++u) {
+    const uint32_t c0 = u * kSuper, c1 = std::min(c0 + (uint32_t)kSuper, n_clusters);
+    double m[3] = {0, 0, 0};
+    for (uint32_t c = c0; c < c1; ++c) m[0] += cluster_ball[c].x, m[1] += cluster_ball[c].y, m[2] += cluster_ball[c].z;
+    const float mf[3] = {(float)(m[0] / (c1 - c0)), (float)(m[1] / (c1 - c0)), (float)(m[2] / (c1 - c0))};
+    double reach = 0.0;
+    for (uint32_t c = c0; c < c1; ++c) {
+      const double dx = (double)cluster_ball[c].x - mf[0], dy = (double)cluster_ball[c].y - mf[1], dz = (double)cluster_ball[c].z - mf[2];
+      reach = std::fmax(reach, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)cluster_ball[c].w);
+    }
+    super_ball[u] = make_float4(mf[0], mf[1], mf[2], round_up(reach * (1.0 + 1e-7)));
+  }
 
   DevScene& d = flat.dev;
   d = DevScene{};
@@ -807,6 +855,7 @@ int rtk::place_scene(rtk_context* ctx, const rtk::FlatScene& flat, rtk_scene_han
   d.sph_tab = (decltype(d.sph_tab))h->d_sph_tab;
   d.sph_ball = (decltype(d.sph_ball))h->d_sph_ball;
   d.cluster_ball = (decltype(d.cluster_ball))h->d_cluster_ball;
+  d.super_ball = (decltype(d.super_ball))h->d_super_ball;
   *out = h;
   return RTK_OK;
 }
@@ -909,6 +958,7 @@ struct Scratch {
   float4 *prim = nullptr, *prim_ball = nullptr, *prim_cluster = nullptr;  // per-camera records
   rtk::DevCounters* counters = nullptr;
   rtk::OpaqueBuffers opaque{};  // hit records of the three-kernel path (null when not needed)
+  const rtk::WavefrontBuffers* wavefront = nullptr;  // node queue of the level-by-level path (null: depth-first kernel)
 };
 
 // A frame in the making: frame_begin, one or more frame_launch, frame_end.
@@ -939,6 +989,47 @@ static int context_records(rtk_context* ctx, size_t pixels, rtk::OpaqueBuffers& 
   }
   out = ctx->opaque;
   return RTK_OK;
+}
+
+// Node queue of the level-by-level path for launches of up to `pixels` pixels, in the context's own
+// buffers: room for kWavefrontNodesPerPixel nodes per pixel, capped (larger launches run in passes).
+// Null when device memory cannot be had: the launch then runs on the depth-first kernel.
+static const rtk::WavefrontBuffers* context_wavefront(rtk_context* ctx, size_t pixels) {
+  rtk::WavefrontBuffers& w = ctx->wavefront;
+  if (!w.host_overflow) {
+    if (hipHostMalloc((void**)&w.host_overflow, sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      w.host_overflow = nullptr;
+      return nullptr;
+    }
+    *w.host_overflow = 0u;
+  }
+  // an earlier launch ran out of room (and was traced again depth first): this scene's trees are
+  // larger than allowed for, so reserve twice the room per pixel from now on
+  if (*static_cast<volatile unsigned int*>(w.host_overflow)) {
+    *w.host_overflow = 0u;
+    w.nodes_per_pixel = std::min(w.nodes_per_pixel * 2u, (1u << rtk::kMaxDepth) - 1u);
+  }
+  const size_t floor_nodes = (size_t)rtk::kBlock * w.nodes_per_pixel;
+  const size_t want = std::min<size_t>(std::max<size_t>(pixels * w.nodes_per_pixel, floor_nodes), ctx->wavefront_max_nodes);
+  if (want < floor_nodes) return nullptr;
+  if (w.cap_nodes >= want) return &w;
+  // an earlier frame's kernels may still use the old buffers
+  if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+  if (w.rays) (void)hipFree(w.rays);
+  if (w.outs) (void)hipFree(w.outs);
+  w.rays = nullptr, w.outs = nullptr, w.cap_nodes = 0;
+  if (!w.ctrl && hipMalloc((void**)&w.ctrl, sizeof(unsigned int) * rtk::kWavefrontCtrlWords) != hipSuccess) w.ctrl = nullptr;
+  if (!w.counters && hipMalloc((void**)&w.counters, sizeof(rtk::DevCounters) * rtk::kCounterShards) != hipSuccess) w.counters = nullptr;
+  if (!w.ctrl || !w.counters || hipMalloc((void**)&w.rays, want * sizeof(rtk::WfNodeRay)) != hipSuccess ||
+      hipMalloc((void**)&w.outs, want * sizeof(rtk::WfNodeOut)) != hipSuccess) {
+    (void)hipGetLastError();
+    if (w.rays) (void)hipFree(w.rays);
+    w.rays = nullptr, w.outs = nullptr;
+    return nullptr;
+  }
+  w.cap_nodes = (uint32_t)want;
+  return &w;
 }
 
 // Orders this call behind the context's previous one (they share per-camera records, counters
@@ -981,7 +1072,7 @@ static int frame_launch(Frame& f, const rtk::Partition& p, float* d_rgb_f32, uin
     RTK_HIP(rtk::launch_render_opaque(f.st, f.scene->dev, f.cam, f.scr.prim, f.scr.prim_ball, f.scr.prim_cluster, t,
                                       f.scr.opaque, f.scr.counters, split ? ctx->ev_rays[f.slot] : nullptr));
   } else {
-    RTK_HIP(rtk::launch_render(f.st, f.scene->dev, f.cam, t, f.scr.counters));
+    RTK_HIP(rtk::launch_render(f.st, f.scene->dev, f.cam, t, f.scr.counters, f.scr.wavefront, f.scr.prim, f.scr.prim_cluster));
   }
   return RTK_OK;
 }
@@ -1009,6 +1100,13 @@ static int context_scratch(rtk_context* ctx, rtk_scene_handle* scene, size_t lau
   if (!scene->dev.any_secondary && rtk::opaque_needs_records(scene->dev)) {
     RTK_HIP(hipSetDevice(ctx->device));
     return context_records(ctx, launch_pixels, scr.opaque);
+  }
+  const rtk::DevScene& ds = scene->dev;
+  const bool by_level = ctx->trace_order == RTK_TRACE_BY_LEVEL ||
+                        (ctx->trace_order == RTK_TRACE_AUTO && rtk::wavefront_applies(ds) && rtk::wavefront_pays(ds, launch_pixels));
+  if (by_level && ds.any_secondary && ds.max_depth >= 2 && ctx->wavefront_max_nodes) {
+    RTK_HIP(hipSetDevice(ctx->device));
+    scr.wavefront = context_wavefront(ctx, launch_pixels);
   }
   return RTK_OK;
 }

@@ -11,6 +11,7 @@ namespace rtk {
 constexpr int kBlock = 256;      // threads per workgroup = one 32x8 pixel tile (4 waves of 8x8)
 constexpr int kGroup = 8;        // records per wavefront early-out branch (one ray per lane)
 constexpr int kBundle = 64;      // records per wavefront-level test (one sphere per lane); arrays are padded to this
+constexpr int kSuper = 8;        // clusters of kBundle spheres per ball of the upper level
 constexpr int kMaxDepth = 8;     // == RTK_MAX_DEPTH_LIMIT
 constexpr uint32_t kMaxLights = 32767;  // == RTK_MAX_LIGHTS: the shadow-ray count of a hit is kept in 15 bits
 
@@ -89,6 +90,7 @@ struct DevScene {
   const RTK_RO float4* sph_tab;        // {cx, cy, cz, kappa |c|^2 - R'^2}: sphere record of the tabulated shadow filter
   const RTK_RO float4* sph_ball;       // {cx, cy, cz, R'}: record of the wavefront-level test; padding has R' = -1e30
   const RTK_RO float4* cluster_ball;   // one ball around each aligned run of kBundle spheres; padded to kBundle with R = -1e30
+  const RTK_RO float4* super_ball;     // one ball around each aligned run of kSuper clusters
   uint32_t n_objects, n_lights, n_spheres, n_spheres_padded, n_planes;
   uint32_t n_clusters_padded;
   uint32_t n_spheres_grouped;  // n_spheres rounded up to kGroup: what the one-ray-per-lane sweeps cover
@@ -124,6 +126,34 @@ struct DevCounters {
   unsigned long long rays_primary, rays_shadow, rays_secondary, exact_tests;
 };
 __device__ __forceinline__ DevCounters* counter_shard(DevCounters* base) { return base + (blockIdx.x % kCounterShards); }
+
+// Level-by-level tracing of scenes with secondary rays (rtk_wavefront.hip): a queued ray, what
+// its node contributes, and the buffers of a context.  Node i of a pass is a camera ray for
+// i < n_roots (no queue entry: the ray is generated from the pixel), else the queue entry
+// rays[i - n_roots]; outs[i] is its result.
+struct WfNodeRay {
+  double o[3], d[3];
+  double weight;
+  uint32_t depth, reserved_;
+};
+struct WfNodeOut {
+  double t[3];                                // the node's own term (flag bit 0)
+  double w_refraction, w_reflection;          // weights of children cut off by the depth limit (flag bits 1, 2)
+  uint32_t child_refraction, child_reflection;  // node indices, 0xffffffff: none
+  uint32_t flags, reserved_[3];
+};
+static_assert(sizeof(WfNodeRay) == 64 && sizeof(WfNodeOut) == 64, "node records are one 64-byte line each");
+constexpr uint32_t kWavefrontCtrlWords = 16;        // nodes so far, overflow flag, one level end per depth
+constexpr uint32_t kWavefrontNodesPerPixel = 6;     // queue room a pass reserves per pixel (its camera ray included), to begin with
+struct WavefrontBuffers {
+  WfNodeRay* rays = nullptr;    // cap_nodes entries
+  WfNodeOut* outs = nullptr;    // cap_nodes entries
+  unsigned int* ctrl = nullptr;  // kWavefrontCtrlWords words
+  DevCounters* counters = nullptr;  // kCounterShards shards: the launch's own ray counts
+  unsigned int* host_overflow = nullptr;  // page-locked host word, set when a launch ran out of queue room
+  uint32_t cap_nodes = 0;
+  uint32_t nodes_per_pixel = kWavefrontNodesPerPixel;  // queue room a pass reserves per pixel
+};
 
 // Intermediate records of the three-kernel path, one entry per pixel of the launch
 // (local tile k, slot s -> index k*256 + s).

@@ -44,6 +44,7 @@ struct rtk_scene_handle {
   void* d_prim_ball = nullptr;     // camera-ray records of the wavefront-level cone test (rebuilt per camera)
   void* d_sph_ball = nullptr;
   void* d_cluster_ball = nullptr;
+  void* d_super_ball = nullptr;
   void* d_prim_cluster = nullptr;  // camera-ray records of the cluster balls (rebuilt per camera)
   void* d_light_filter = nullptr;
   void* d_k_table = nullptr;
@@ -75,6 +76,11 @@ struct rtk_context {
   // intermediate records of the three-kernel path (grown on demand, kept for the next frame)
   rtk::OpaqueBuffers opaque{};
   size_t cap_opaque = 0;
+  // node queue of the level-by-level path for scenes with secondary rays (grown on demand up to
+  // wavefront_max_nodes; 0 there keeps such scenes on the depth-first kernel)
+  rtk::WavefrontBuffers wavefront{};
+  uint32_t wavefront_max_nodes = 0;
+  uint32_t trace_order = RTK_TRACE_AUTO;
   // page-locked staging for scene uploads (grown on demand)
   unsigned char* h_stage = nullptr;
   size_t cap_stage = 0;

@@ -6,6 +6,11 @@
 
 namespace rtk {
 
+// A kernel launch reports failure only through hipGetLastError, which also returns whatever error an
+// earlier, unrelated call on this thread left behind (a probe of a pageable pointer, say).  Every
+// launch wrapper starts by dropping that, so that what it reads after its launch is its own.
+inline void drop_stale_error() { (void)hipGetLastError(); }
+
 // Lights fused per shadow sweep for a scene with n_lights lights (1, 2, 4 or 8).
 int light_batch_for(uint32_t n_lights);
 
@@ -17,8 +22,24 @@ hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamer
 
 // Renders the tiles selected by T.
 // `counters` holds kCounterShards shards followed by one more element whose first word is the
-// launch's work counter; all of it zeroed before the launch.
-hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const RenderTarget& T, DevCounters* counters);
+// launch's work counter; all of it zeroed before the launch.  wf (may be null): queue buffers; a scene
+// with secondary rays and a depth limit of 2 or more is then traced level by level (the caller decides
+// whether that pays, see wavefront_applies / wavefront_pays); prim / prim_cluster are the per-camera records.
+hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const RenderTarget& T, DevCounters* counters,
+                         const WavefrontBuffers* wf = nullptr, const float4* prim = nullptr, const float4* prim_cluster = nullptr);
+
+// Level-by-level tracing (rtk_wavefront.hip).  wavefront_applies: the scene has secondary rays to
+// queue and enough objects for the cluster sweeps.  launch_render_wavefront renders the tiles of T
+// in passes that fit B and adds its ray counts to `counters`, unless some pass ran out of queue
+// room: then the word at wavefront_overflow_flag(B) is non-zero after the launch, nothing has been
+// added to `counters`, and the caller renders T again with a kernel that needs no queue.
+bool wavefront_applies(const DevScene& S);
+// ... and a launch of that many pixels is expected to finish sooner that way than depth first.
+bool wavefront_pays(const DevScene& S, uint64_t launch_pixels);
+hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
+                                   const float4* prim_cluster, const RenderTarget& T, const WavefrontBuffers& B,
+                                   DevCounters* counters);
+const unsigned int* wavefront_overflow_flag(const WavefrontBuffers& B);
 
 // Same for scenes without reflective or transparent materials: ray kernel(s) (camera +
 // shadow rays) and a shading kernel, with intermediate records in B.  `after_rays`, when not

@@ -22,8 +22,7 @@
 // No MFMA (nothing here is a dense contraction); HBM traffic is the framebuffer store; the
 // scene records stay in L2.
 
-#include "rtk_shading.h"
-#include "rtk_sweeps.h"
+#include "rtk_trace.h"
 #include "rtk_kernels.h"
 
 #include <algorithm>
@@ -31,238 +30,6 @@
 #pragma clang fp contract(off)
 
 namespace rtk {
-
-// ------------------------------------------------------------------------------------
-// `Scene::trace` (src/scene.rs:136-296) for one ray per thread, evaluated iteratively:
-// child colours enter their parent linearly with scalar factors (reflectivity,
-// transparency, Schlick reflectance), so each node adds weight * surface to the pixel and
-// pushes its children with the product weight.  SECONDARY = false would remove the stack;
-// every kernel built from this file traces secondary rays.
-struct StackEntry {
-  double ox, oy, oz, dx, dy, dz, weight;
-  int depth;
-};
-
-// Scenes of a handful of objects (the reference's bundled scene has three): every object is
-// intersected exactly, in object order; no filter records, no clusters.
-constexpr uint32_t kBruteObjects = 8;
-template <bool TRACK>
-__device__ __forceinline__ void closest_brute(const DevScene& S, bool active, V3 o, V3 d, Closest& best, bool& graze) {
-  closest_init(best);
-  constexpr bool track = TRACK;
-  if (!active) return;
-  for (uint32_t obj = 0; obj < S.n_objects; ++obj) {
-    double t0, t1;
-    const int n = intersect_object(S.objects[obj], o, d, 0.0, t0, t1);
-    if (n >= 1) closest_consider(best, t0, obj, track);
-    if (n == 2) closest_consider(best, t1, obj, track);
-    if (n == 2 && track && fabs(t0 - t1) < 0.00001) graze = true;
-  }
-}
-
-// n1 of `LightingData::compute_refractivity` (src/scene/lighting.rs:81-116) by the letter, for the
-// rays whose hit list holds a sphere with both roots within 1e-5 of each other.  The reference
-// walks the sorted list (stable: ties in object order, a sphere's smaller root first) up to the
-// first entry that `Hit::eq` (same object, distances within 1e-5: src/scene.rs:354-364) calls the
-// winner -- the winner itself, or the same sphere's other root just before it -- and keeps a list
-// of "containers": every entry is pushed, except that an entry equal to one already there removes
-// it and stays out, which only the two close roots of one sphere can do to each other.  n1 is the
-// refractive index of the last container at that point, 1.0 without one.  (n2 is always the
-// winner's own index: nothing before the stopping entry equals it.)  Every object is intersected
-// again, exactly; this runs for a handful of rays per frame at most.
-__device__ __forceinline__ double literal_n1(const DevScene& S, V3 o, V3 d, uint32_t own, double t_win) {
-  double b_t = t_win;
-  uint32_t b_root = 0;
-  {
-    double t0, t1;
-    const int n = intersect_object(S.objects[own], o, d, 0.0, t0, t1);
-    if (n == 2 && t_win != t0) {  // the winner is the larger root
-      b_root = 1;
-      if (fabs(t0 - t1) < 0.00001) b_t = t0, b_root = 0;  // ... and its sibling already counts as the winner
-    }
-  }
-  double last_t = -DBL_MAX;
-  uint32_t last_obj = 0xffffffffu, last_root = 0;
-  for (uint32_t obj = 0; obj < S.n_objects; ++obj) {
-    double t[2];
-    const int n = intersect_object(S.objects[obj], o, d, 0.0, t[0], t[1]);
-    if (n == 0) continue;
-    bool before[2] = {false, false};
-    for (int r = 0; r < n; ++r)
-      before[r] = t[r] < b_t || (t[r] == b_t && (obj < own || (obj == own && (uint32_t)r < b_root)));
-    if (n == 2 && before[0] && before[1] && fabs(t[0] - t[1]) < 0.00001) continue;  // the second root removes the first
-    for (int r = 0; r < n; ++r)
-      if (before[r] && (last_obj == 0xffffffffu || t[r] > last_t ||
-                        (t[r] == last_t && (obj > last_obj || (obj == last_obj && (uint32_t)r > last_root)))))
-        last_t = t[r], last_obj = obj, last_root = (uint32_t)r;
-  }
-  return last_obj == 0xffffffffu ? 1.0 : S.objects[last_obj].refractivity;
-}
-// `Scene::is_shadowed` (src/scene.rs:208-225): one shadow ray per light until one is blocked.
-__device__ __forceinline__ bool shadow_brute(const DevScene& S, bool active, V3 p, unsigned& n_rays) {
-  if (!active) return false;
-  for (uint32_t k = 0; k < S.n_lights; ++k) {
-    ++n_rays;
-    const RTK_RO DevLight& L = S.lights[k];
-    const V3 lv = ld3(L.pos) - p;
-    const double lw = L.pos[3] - 1.0;
-    const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
-    const V3 d = {lv.x / m, lv.y / m, lv.z / m};
-    const double dw = lw / m;
-    for (uint32_t obj = 0; obj < S.n_objects; ++obj) {
-      double t0, t1;
-      const int n = intersect_object(S.objects[obj], p, d, dw, t0, t1);
-      if ((n >= 1 && t0 > 0.0 && t0 < m) || (n == 2 && t1 > 0.0 && t1 < m)) return true;
-    }
-  }
-  return false;
-}
-
-// One node of the ray tree: `trace_inner` (src/scene.rs:141-153) for the ray (ro, rd) that enters the
-// pixel's colour with factor `weight`: closest hit, `apply_lighting` (src/scene.rs:172-205) with its
-// shadow rays, and the node's children pushed on the lane's stack.  camera_sweep: the ray is a camera
-// ray and the per-camera records may be used for its sweep.
-template <bool SECONDARY, bool PRIMARY_FILTER, int LB, bool WIDE, bool BRUTE, bool TRACK>
-__device__ __forceinline__ void trace_step(const DevScene& S, const float4* __restrict__ prim,
-                                           const float4* __restrict__ prim_cluster, bool have, bool camera_sweep, V3 ro, V3 rd,
-                                           double weight, int depth, StackEntry* stack, int& sp, V3& color, unsigned& c_primary,
-                                           unsigned& c_shadow, unsigned& c_secondary, unsigned& c_exact) {
-  const V3 scene_ambient = ld3(S.ambient);
-  if (have) {
-    if (depth == 0)
-      ++c_primary;
-    else
-      ++c_secondary;
-  }
-  Closest best;
-  bool graze = false;  // some sphere has both roots within 1e-5 of each other on this ray
-  if (BRUTE)
-    closest_brute<TRACK>(S, have, ro, rd, best, graze);
-  else if (PRIMARY_FILTER && camera_sweep)
-    closest_primary<TRACK>(S, prim, prim_cluster, have, ro, rd, best, c_exact, graze);
-  else
-    closest_general<WIDE, TRACK>(S, have, ro, rd, best, c_exact, graze);
-
-  const bool hit = have && best.obj != 0xffffffffu;
-  if (have && !hit) color = color + scene_ambient * weight;  // trace_inner: miss -> ambient_color
-
-  // --- apply_lighting (src/scene.rs:172-205) ---
-  V3 over = {0, 0, 0}, normal = {0, 0, 1}, eye = {0, 0, 1}, tex = {0, 0, 0};
-  uint32_t obj = hit ? best.obj : 0u;
-  if (hit) {
-    const RTK_RO DevObject& ob = S.objects[obj];
-    HitGeom g = lighting_data(ob, ro, rd, best.t);
-    over = g.over;
-    normal = g.normal;
-    eye = g.eye;
-    tex = sample_texture_at(S, ob, obj, g.objp);
-    if (SECONDARY) {
-      // children first, so that nothing of them stays live across the shadow sweep
-      const double reflectivity = ob.reflectivity, transparency = ob.transparency;
-      const bool has_refl = !is_approx_zero(reflectivity);   // reflected_color early-out
-      const bool has_refr = !is_approx_zero(transparency);   // refracted_color early-out
-      if (has_refl || has_refr) {
-        double n2 = ob.refractivity;
-        // n1: material of the entry just before the hit in the sorted list, else 1.0.  When
-        // every refractivity in the scene is 1.0 (track_n1 == 0) that is 1.0 either way.
-        // Two roots that close make the reference's container list drop entries: then by the letter.
-        double n1 = 1.0;
-        if constexpr (TRACK) {
-          if (graze)
-            n1 = literal_n1(S, ro, rd, obj, best.t);
-          else if (best.prev_obj != 0xffffffffu)
-            n1 = S.objects[best.prev_obj].refractivity;
-        }
-        const double cos_i = dot3(eye, normal);
-        double w_refl = weight * reflectivity, w_refr = weight * transparency;
-        if (reflectivity > 0.0 && transparency > 0.0) {
-          double reflectance = shlick(n1, n2, cos_i);
-          w_refl = weight * (reflectivity * reflectance);
-          w_refr = weight * (transparency * (1.0 - reflectance));
-        }
-        const bool child_traces = (uint32_t)(depth + 1) < S.max_depth;
-        if (has_refr) {  // src/scene.rs:244-272
-          double n_ratio = n1 / n2;
-          double sin_t2 = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
-          if (!(sin_t2 > 1.0)) {
-            double cos_t = sqrt(1.0 - sin_t2);
-            V3 dir = normal * (n_ratio + cos_i - cos_t) - eye * n_ratio;  // the reference's `+`
-            if (child_traces) {
-              StackEntry& e = stack[sp++];
-              e.ox = g.under.x, e.oy = g.under.y, e.oz = g.under.z;
-              e.dx = dir.x, e.dy = dir.y, e.dz = dir.z;
-              e.weight = w_refr;
-              e.depth = depth + 1;
-            } else {
-              color = color + scene_ambient * w_refr;  // trace_inner(depth >= MAX_DEPTH)
-            }
-          }
-        }
-        if (has_refl) {  // src/scene.rs:228-241
-          if (child_traces) {
-            StackEntry& e = stack[sp++];
-            e.ox = g.over.x, e.oy = g.over.y, e.oz = g.over.z;
-            e.dx = g.reflect.x, e.dy = g.reflect.y, e.dz = g.reflect.z;
-            e.weight = w_refl;
-            e.depth = depth + 1;
-          } else {
-            color = color + scene_ambient * w_refl;
-          }
-        }
-      }
-    }
-  }
-
-  const bool in_shadow = BRUTE ? shadow_brute(S, hit, over, c_shadow) : shadow_sweeps<LB, WIDE>(S, hit, over, c_shadow, c_exact);
-
-  if (hit) {
-    const RTK_RO DevObject& ob = S.objects[obj];
-    V3 surface = scene_ambient;
-    for (uint32_t k = 0; k < S.n_lights; ++k)
-      surface = surface + phong_lighting(S.lights[k], ob, tex, over, eye, normal, in_shadow);
-    color = color + surface * weight;
-  }
-}
-
-// `Scene::trace` (src/scene.rs:136-138) for one ray per lane: the tree is walked with a stack per lane,
-// every lane of the wavefront taking one node per round until all stacks are empty.
-template <bool SECONDARY, bool PRIMARY_FILTER, int LB, bool WIDE, bool BRUTE, bool TRACK>
-__device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restrict__ prim,
-                                        const float4* __restrict__ prim_cluster, bool valid, V3 o,
-                                        V3 d, unsigned& c_primary, unsigned& c_shadow, unsigned& c_secondary,
-                                        unsigned& c_exact) {
-  V3 color = {0, 0, 0};
-  StackEntry stack[SECONDARY ? kMaxDepth + 1 : 1];
-  int sp = 0;
-  // current ray
-  V3 ro = o, rd = d;
-  double weight = 1.0;
-  int depth = 0;
-  bool have = valid && S.max_depth > 0;
-  if (valid && S.max_depth == 0) color = ld3(S.ambient);  // trace_inner(depth 0 >= MAX_DEPTH)
-
-  for (int iter = 0;; ++iter) {
-    if (SECONDARY) {
-      if (iter > 0) {
-        have = sp > 0;
-        if (have) {
-          --sp;
-          const StackEntry& e = stack[sp];
-          ro = {e.ox, e.oy, e.oz};
-          rd = {e.dx, e.dy, e.dz};
-          weight = e.weight;
-          depth = e.depth;
-        }
-      }
-      if (!__any(have)) break;  // the wavefront has run out of rays
-    } else if (iter > 0) {
-      break;
-    }
-    trace_step<SECONDARY, PRIMARY_FILTER, LB, WIDE, BRUTE, TRACK>(S, prim, prim_cluster, have, iter == 0, ro, rd, weight, depth, stack,
-                                                                  sp, color, c_primary, c_shadow, c_secondary, c_exact);
-  }
-  return color;
-}
 
 // ------------------------------------------------------------------------------------
 // `Camera::render` (src/scene/cameras.rs:72-85) for scenes with reflective or transparent
@@ -342,7 +109,9 @@ __global__ void __launch_bounds__(kBlock, 4) render_small_kernel(DevScene S, Dev
 
 template <int LB, bool WIDE, bool TRACK>
 __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera C, RenderTarget T, DevCounters* counters,
-                                                        unsigned int* work) {
+                                                        unsigned int* work, const unsigned int* only_if) {
+  // the second try of a launch whose first (level by level) ran out of queue room: nothing to do otherwise
+  if (only_if && *only_if == 0u) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t n_patches = T.n_local_tiles * 4u;
   const V3 origin = ld3(C.origin);
@@ -411,9 +180,11 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera
       weight = e.weight;
       depth = e.depth;
     }
-    if (__any(have))
-      trace_step<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, weight, depth, stack, sp, color,
-                                                      c_primary, c_shadow, c_secondary, c_exact);
+    if (__any(have)) {
+      StackSink sink{stack, sp, color};
+      trace_step<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, weight, depth, sink, c_primary,
+                                                      c_shadow, c_secondary, c_exact);
+    }
 
     // pixels whose tree is done
     if (busy && sp == 0) {
@@ -624,12 +395,12 @@ constexpr uint32_t kWideScene = 256;
 
 template <bool WIDE, bool TRACK>
 static hipError_t launch_render_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, const DevCamera& C, const RenderTarget& T,
-                                   DevCounters* counters, unsigned int* work) {
+                                   DevCounters* counters, unsigned int* work, const unsigned int* only_if) {
   switch (lb) {
-    case 1: hipLaunchKernelGGL((render_kernel<1, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, counters, work); break;
-    case 2: hipLaunchKernelGGL((render_kernel<2, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, counters, work); break;
-    case 4: hipLaunchKernelGGL((render_kernel<4, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, counters, work); break;
-    default: hipLaunchKernelGGL((render_kernel<8, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, counters, work); break;
+    case 1: hipLaunchKernelGGL((render_kernel<1, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, counters, work, only_if); break;
+    case 2: hipLaunchKernelGGL((render_kernel<2, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, counters, work, only_if); break;
+    case 4: hipLaunchKernelGGL((render_kernel<4, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, counters, work, only_if); break;
+    default: hipLaunchKernelGGL((render_kernel<8, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, counters, work, only_if); break;
   }
   return hipGetLastError();
 }
@@ -643,6 +414,7 @@ int light_batch_for(uint32_t n_lights) {
 
 hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamera& C, float4* prim, float4* prim_ball,
                                float4* prim_cluster, DevCounters* counters) {
+  drop_stale_error();
   constexpr size_t kCounterBytes = sizeof(DevCounters) * kCounterSlots;
   static_assert(kCounterBytes % sizeof(unsigned long long) == 0, "counters are cleared as 64-bit words");
   if (S.n_spheres_padded == 0) return hipMemsetAsync(counters, 0, kCounterBytes, st);
@@ -653,7 +425,9 @@ hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamer
   return hipGetLastError();
 }
 
-hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const RenderTarget& T, DevCounters* counters) {
+hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const RenderTarget& T, DevCounters* counters,
+                         const WavefrontBuffers* wf, const float4* prim, const float4* prim_cluster) {
+  drop_stale_error();
   if (T.n_local_tiles == 0) return hipSuccess;
   // TRACK kernels (some refractive index differs from the others) carry the entry before the winner
   // and the literal n1 evaluation; the others drop both
@@ -665,6 +439,14 @@ hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, 
       hipLaunchKernelGGL((render_small_kernel<false>), dim3(T.n_local_tiles), dim3(kBlock), 0, st, S, C, T, counters);
     return hipGetLastError();
   }
+  // Level by level where the scene has secondary rays to queue; the depth-first kernel below then
+  // only runs (behind the flag) for a launch whose children did not fit the queue.
+  const unsigned int* only_if = nullptr;  // (scenes of a handful of objects, above, are never queued)
+  if (wf && wf->cap_nodes >= kBlock * wf->nodes_per_pixel && prim && prim_cluster && S.any_secondary && S.max_depth >= 2) {
+    const hipError_t we = launch_render_wavefront(st, S, C, prim, prim_cluster, T, *wf, counters);
+    if (we != hipSuccess) return we;
+    only_if = wavefront_overflow_flag(*wf);
+  }
   // Persistent wavefronts draw 8x8 patches from the launch's work counter (the word behind the
   // counter shards): enough workgroups to fill the GPU
   // twice over at four wavefronts per SIMD, no more than there are tiles.
@@ -675,10 +457,10 @@ hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, 
   dim3 grid(std::min<uint32_t>(T.n_local_tiles, kPersistentGroups));
   const int lb = light_batch_for(S.n_lights);
   if (S.n_spheres >= kWideScene)
-    return track ? launch_render_lb<true, true>(lb, grid, st, S, C, T, counters, work)
-                 : launch_render_lb<true, false>(lb, grid, st, S, C, T, counters, work);
-  return track ? launch_render_lb<false, true>(lb, grid, st, S, C, T, counters, work)
-               : launch_render_lb<false, false>(lb, grid, st, S, C, T, counters, work);
+    return track ? launch_render_lb<true, true>(lb, grid, st, S, C, T, counters, work, only_if)
+                 : launch_render_lb<true, false>(lb, grid, st, S, C, T, counters, work, only_if);
+  return track ? launch_render_lb<false, true>(lb, grid, st, S, C, T, counters, work, only_if)
+               : launch_render_lb<false, false>(lb, grid, st, S, C, T, counters, work, only_if);
 }
 
 template <bool WIDE, bool TRACK>
@@ -695,6 +477,7 @@ static hipError_t launch_trace_rays_lb(int lb, dim3 grid, hipStream_t st, const 
 
 hipError_t launch_trace_rays(hipStream_t st, const DevScene& S, const double* origins, const double* directions, uint64_t n,
                              double* colors, DevCounters* counters) {
+  drop_stale_error();
   if (n == 0) return hipSuccess;
   dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
   const int lb = light_batch_for(S.n_lights);
@@ -707,6 +490,7 @@ hipError_t launch_trace_rays(hipStream_t st, const DevScene& S, const double* or
 }
 hipError_t launch_untile(hipStream_t st, uint32_t width, uint32_t height, uint32_t world, uint64_t rgb_stride_floats,
                          uint64_t px_stride_pixels, const float* rgb_c, float* rgb_f, const uint8_t* px_c, uint8_t* px_f) {
+  drop_stale_error();
   const uint32_t tiles_x = (width + 31u) / 32u, tiles_y = (height + 7u) / 8u;
   const uint32_t n_tiles = tiles_x * tiles_y;
   if (n_tiles == 0) return hipSuccess;
@@ -718,6 +502,7 @@ hipError_t launch_untile(hipStream_t st, uint32_t width, uint32_t height, uint32
 
 hipError_t launch_resolve(hipStream_t st, uint32_t width, uint32_t height, uint32_t s, const float* samples, float* rgb,
                           uint8_t* rgba8) {
+  drop_stale_error();
   const uint64_t pixels = (uint64_t)width * height;
   if (pixels == 0) return hipSuccess;
   hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((pixels + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, width, height, s,
@@ -726,6 +511,7 @@ hipError_t launch_resolve(hipStream_t st, uint32_t width, uint32_t height, uint3
 }
 
 hipError_t launch_resolve_tiles(hipStream_t st, uint64_t n_tiles, uint32_t s, const float* samples, float* rgb, uint8_t* rgba8) {
+  drop_stale_error();
   const uint64_t pixels = n_tiles * (256u / (s * s));
   if (pixels == 0) return hipSuccess;
   hipLaunchKernelGGL(resolve_tiles_kernel, dim3((unsigned)((pixels + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pixels, s,
@@ -736,6 +522,7 @@ hipError_t launch_resolve_tiles(hipStream_t st, uint64_t n_tiles, uint32_t s, co
 hipError_t launch_untile_sampled(hipStream_t st, uint32_t width, uint32_t height, uint32_t s, uint32_t world,
                                  uint64_t rgb_stride_floats, uint64_t px_stride_pixels, const float* rgb_c, float* rgb_f,
                                  const uint8_t* px_c, uint8_t* px_f) {
+  drop_stale_error();
   const uint64_t pixels = (uint64_t)width * height;
   if (pixels == 0) return hipSuccess;
   const uint32_t tiles_x = (uint32_t)(((uint64_t)width * s + 31u) / 32u);

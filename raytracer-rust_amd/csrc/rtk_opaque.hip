@@ -716,6 +716,7 @@ __global__ void __launch_bounds__(kBlock, 5) render_uniform_kernel(DevScene S, D
 hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
                                 const float4* prim_ball, const float4* prim_cluster, const RenderTarget& T,
                                 const OpaqueBuffers& B, DevCounters* counters, hipEvent_t after_rays) {
+  drop_stale_error();
   if (T.n_local_tiles == 0) return after_rays ? hipEventRecord(after_rays, st) : hipSuccess;
   const dim3 tiles(T.n_local_tiles), block(kBlock);
   hipError_t e = hipSuccess;

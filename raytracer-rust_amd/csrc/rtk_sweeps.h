@@ -87,7 +87,8 @@ __device__ __forceinline__ void sweep_primary(const DevScene& S, const float4* _
 // R_e = R sqrt(1 + 2 |rho| max(-s, 0) + R^2 rho^2) of c, s = u.g (rho <= 0 for lights with
 // w in [0, 1]).  For a cluster ball {C, Rc} around its members' balls, with s_C = (p - C).g:
 //     dist(C, line) <= Rc + r_max |rho| max(Rc - s_C, 0) + r_max^3 rho^2 / 2
-// is necessary for any member to be touched (r_max = largest sphere radius of the scene).
+// is necessary for any member to be touched (r_max = largest sphere radius of the scene).  The same
+// holds for any ball that contains the members' balls: the balls of whole groups of clusters.
 template <int NR, bool WIDE, typename ExactFn, typename DoneFn>
 __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, float px, float py, float pz,
                                              const float (&gx)[NR], const float (&gy)[NR], const float (&gz)[NR],
@@ -106,26 +107,36 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
   }
   // covers the FP32 rounding of the point, the centres, the directions and the arithmetic below
   const float pad = grow * 1.01f + 16.0f * kEps32 * (fabsf(px) + fabsf(py) + fabsf(pz) + S.c_max);
-  for (uint32_t first = 0; wave_live && first < S.n_spheres_grouped; first += kBundle) {
-    bool reach = active;
-    if (cull) {
-      const float4 cl = S.cluster_ball[first / kBundle];
-      const float ux = px - cl.x, uy = py - cl.y, uz = pz - cl.z;
-      const float room = cl.w + pad;
-      bool pass = false;
+  // can any of this lane's rays touch a sphere inside the ball {C, Rc}?
+  auto may_reach = [&](const float4 cl) {
+    const float ux = px - cl.x, uy = py - cl.y, uz = pz - cl.z;
+    const float room = cl.w + pad;
+    bool pass = false;
 #pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const float s = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], ux * gx[r]));
-        const float qx = __builtin_fmaf(-s, gx[r], ux), qy = __builtin_fmaf(-s, gy[r], uy), qz = __builtin_fmaf(-s, gz[r], uz);
-        const float d2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
-        const float t = fmaxf(cl.w - s, 0.0f) * (1.0f + 8.0f * kEps32);
-        const float rr = __builtin_fmaf(t, S.r_max * lrho[r], room) * (1.0f + 4.0f * kEps32);
-        // s = (p - C).g: beyond room, every point of the ball has a negative ray parameter
-        const bool behind = forward && s > room;
-        pass |= !behind && rr >= 0.0f && __builtin_fmaf(rr, rr, -d2) >= 0.0f;
-      }
-      reach = active && pass;
+    for (int r = 0; r < NR; ++r) {
+      const float s = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], ux * gx[r]));
+      const float qx = __builtin_fmaf(-s, gx[r], ux), qy = __builtin_fmaf(-s, gy[r], uy), qz = __builtin_fmaf(-s, gz[r], uz);
+      const float d2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+      const float t = fmaxf(cl.w - s, 0.0f) * (1.0f + 8.0f * kEps32);
+      const float rr = __builtin_fmaf(t, S.r_max * lrho[r], room) * (1.0f + 4.0f * kEps32);
+      // s = (p - C).g: beyond room, every point of the ball has a negative ray parameter
+      const bool behind = forward && s > room;
+      pass |= !behind && rr >= 0.0f && __builtin_fmaf(rr, rr, -d2) >= 0.0f;
     }
+    return pass;
+  };
+  // Two levels: kSuper consecutive clusters (a subtree of the k-d split that ordered the spheres)
+  // share one ball; a wavefront none of whose rays can reach it skips all of them at once.
+  constexpr uint32_t kSuperSpheres = kSuper * kBundle;
+  for (uint32_t super_first = 0; wave_live && super_first < S.n_spheres_grouped; super_first += kSuperSpheres) {
+    if (S.n_spheres_grouped > kSuperSpheres) {
+      const bool reach_super = active && (!cull || may_reach(S.super_ball[super_first / kSuperSpheres]));
+      if (!__any(reach_super)) continue;
+    }
+    const uint32_t super_end = min(super_first + kSuperSpheres, S.n_spheres_grouped);
+    for (uint32_t first = super_first; wave_live && first < super_end; first += kBundle) {
+    bool reach = active;
+    if (cull) reach = active && may_reach(S.cluster_ball[first / kBundle]);
     const unsigned long long reach_mask = __builtin_amdgcn_ballot_w64(reach);
     if (reach_mask == 0ull) continue;
     if (WIDE && __builtin_popcountll(reach_mask) <= kTransposeBelow && S.n_spheres_grouped - first >= 32u) {
@@ -218,6 +229,7 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
         wave_live = __any(active);
         if (!wave_live) break;
       }
+    }
     }
   }
 }

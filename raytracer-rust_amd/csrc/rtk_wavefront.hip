@@ -1,0 +1,302 @@
+// rtk_wavefront.hip -- scenes with reflective or transparent materials, traced level by level.
+//
+// The ray tree of a pixel (`Scene::trace`, src/scene.rs:136-296) has up to 2^max_depth - 1 nodes,
+// and one lane walking it depth first needs one wavefront-wide sweep per node: a pixel of 60 nodes
+// keeps its wavefront alive for 60 sweeps, long after the pixels around it are done, and the frame
+// is not finished before its slowest pixel is.  Here the nodes of ALL pixels are traced one tree
+// level at a time instead: the camera rays first; the children they produce are appended to a queue
+// in device memory and traced by the next launch, one lane per node, every wavefront full; and so
+// on down to the depth limit.  The longest dependency chain of a frame is max_depth launches.
+//
+// What a node adds to its pixel is not summed on the spot -- f64 sums depend on their order, and the
+// order must be that of the depth-first evaluation whatever order the nodes were traced in.  Every
+// node stores its terms and the queue positions of its children (NodeOut); when all levels are done
+// one lane per pixel walks the pixel's tree depth first over these records, reflected subtree before
+// refracted subtree, and adds the terms exactly as the one-lane evaluation (StackSink in rtk_trace.h)
+// would have, then stores the pixel (src/graphics.rs:59-74).
+//
+// The queue has a fixed capacity.  A frame is cut into passes of as many tiles as are sure to have
+// their camera rays and a generous number of children fit; should the children of a pass not fit
+// after all, a flag is raised, and the caller re-renders the launch with the depth-first kernel
+// (which needs no queue), guarded by that flag.
+#include "rtk_trace.h"
+#include "rtk_kernels.h"
+
+#include <algorithm>
+
+#pragma clang fp contract(off)
+
+namespace rtk {
+
+constexpr uint32_t kNoNode = 0xffffffffu;
+constexpr uint32_t kHasTerm = 1u, kUntracedRefraction = 2u, kUntracedReflection = 4u;
+
+// words of the control block
+constexpr int kCtrlNodes = 0;     // nodes handed out so far in this pass (camera rays included)
+constexpr int kCtrlOverflow = 1;  // some child found no room: the launch is to be rendered again
+constexpr int kCtrlClaim = 2;     // next node of the current level no wavefront has taken yet
+constexpr int kCtrlLevelEnd = 3;  // [kCtrlLevelEnd + l]: one past the last node of level l
+
+// Result sink of trace_step for one node: keeps the node's terms, appends its children to the queue.
+struct QueueSink {
+  V3 t = {0, 0, 0};
+  double w_refraction = 0.0, w_reflection = 0.0;
+  uint32_t child_refraction = kNoNode, child_reflection = kNoNode, flags = 0;
+  WfNodeRay* rays;
+  unsigned int* ctrl;
+  uint32_t n_roots, cap_nodes;
+
+  __device__ __forceinline__ QueueSink(const WavefrontBuffers& B, uint32_t roots)
+      : rays(B.rays), ctrl(B.ctrl), n_roots(roots), cap_nodes(B.cap_nodes) {}
+  __device__ __forceinline__ void term(V3 v, double w) {
+    t = v * w;
+    flags |= kHasTerm;
+  }
+  __device__ __forceinline__ void untraced_child(bool reflection, V3, double w) {
+    if (reflection)
+      w_reflection = w, flags |= kUntracedReflection;
+    else
+      w_refraction = w, flags |= kUntracedRefraction;
+  }
+  // One atomic per wavefront: the lanes that push a child here take consecutive queue positions.
+  __device__ __forceinline__ void child(bool reflection, V3 o, V3 d, double w, int depth) {
+    const unsigned long long pushing = __builtin_amdgcn_ballot_w64(true);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t leader = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(pushing));
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pushing >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushing, 0u));
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(&ctrl[kCtrlNodes], (unsigned int)__builtin_popcountll(pushing));
+    base = (unsigned int)__builtin_amdgcn_readlane((int)base, (int)leader);
+    const uint32_t at = base + rank;
+    if (at < cap_nodes) {
+      WfNodeRay& r = rays[at - n_roots];
+      r.o[0] = o.x, r.o[1] = o.y, r.o[2] = o.z;
+      r.d[0] = d.x, r.d[1] = d.y, r.d[2] = d.z;
+      r.weight = w;
+      r.depth = (uint32_t)depth;
+      r.reserved_ = 0;
+      if (reflection)
+        child_reflection = at;
+      else
+        child_refraction = at;
+    } else {
+      ctrl[kCtrlOverflow] = 1u;
+    }
+  }
+  __device__ __forceinline__ void store(WfNodeOut& out) const {
+    out.t[0] = t.x, out.t[1] = t.y, out.t[2] = t.z;
+    out.w_refraction = w_refraction;
+    out.w_reflection = w_reflection;
+    out.child_refraction = child_refraction;
+    out.child_reflection = child_reflection;
+    out.flags = flags;
+  }
+};
+
+__device__ __forceinline__ void add_counters(DevCounters* counters, unsigned c_primary, unsigned c_shadow, unsigned c_secondary,
+                                             unsigned c_exact) {
+  c_primary = wave_sum(c_primary);
+  c_shadow = wave_sum(c_shadow);
+  c_secondary = wave_sum(c_secondary);
+  c_exact = wave_sum(c_exact);
+  if ((threadIdx.x & 63u) == 0) {
+    if (c_primary) atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)c_primary);
+    if (c_shadow) atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)c_shadow);
+    if (c_secondary) atomicAdd(&counter_shard(counters)->rays_secondary, (unsigned long long)c_secondary);
+    if (c_exact) atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)c_exact);
+  }
+}
+
+// Start of a pass or of a level: [kCtrlLevelEnd + level] = nodes so far (at most the capacity).
+// set_nodes != 0 (start of a pass): the camera rays of the pass are nodes 0 .. set_nodes - 1.
+__global__ void wf_mark_kernel(unsigned int* ctrl, uint32_t level, uint32_t cap_nodes, uint32_t set_nodes) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (set_nodes) ctrl[kCtrlNodes] = set_nodes;
+  ctrl[kCtrlLevelEnd + level] = min(ctrl[kCtrlNodes], cap_nodes);
+  if (level > 0) ctrl[kCtrlClaim] = ctrl[kCtrlLevelEnd + level - 1];
+}
+
+// Level 0: the camera rays of the pass's tiles (ray generation: src/scene/cameras.rs:52-69 with the
+// matrix inverse hoisted to the host).  One workgroup per 32x8 tile, one lane per pixel; node index
+// = workgroup * 256 + thread.
+template <int LB, bool WIDE, bool TRACK>
+__global__ void __launch_bounds__(kBlock, 4) wf_primary_kernel(DevScene S, DevCamera C, RenderTarget T, const float4* __restrict__ prim,
+                                                            const float4* __restrict__ prim_cluster, uint32_t tile_base,
+                                                            WavefrontBuffers B) {
+  const uint32_t k = tile_base + blockIdx.x;
+  const TileRef tr = tile_ref(T, k);
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t lx = (wave << 3) | (lane & 7u), ly = lane >> 3;
+  const uint32_t x = tr.tx * 32u + lx, y = tr.ty * 8u + ly;
+  const bool valid = x < C.width && y < C.height;
+  const V3 origin = ld3(C.origin);
+  const V3 dir = camera_ray_direction(C, x, y);
+  unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
+  QueueSink sink(B, gridDim.x * kBlock);
+  trace_step<true, true, LB, WIDE, false, TRACK>(S, prim, prim_cluster, valid, true, origin, dir, 1.0, 0, sink, c_primary, c_shadow,
+                                                 c_secondary, c_exact);
+  sink.store(B.outs[blockIdx.x * kBlock + threadIdx.x]);
+  add_counters(B.counters, c_primary, c_shadow, c_secondary, c_exact);
+}
+
+// Level l >= 1: the nodes queued by level l - 1, one lane per node, 64 consecutive queue entries per
+// wavefront (children of neighbouring parents, pushed side by side).  The claim counter may run past
+// the level's end by 64 per wavefront of the launch: far from wrapping for queues of up to 2^31 nodes.
+template <int LB, bool WIDE, bool TRACK>
+__global__ void __launch_bounds__(kBlock, 4) wf_level_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
+  const uint32_t end = B.ctrl[kCtrlLevelEnd + level];
+  unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
+  // wavefronts take 64 nodes at a time from the level's counter: nodes cost very different amounts
+  for (;;) {
+    unsigned int base = 0;
+    if ((threadIdx.x & 63u) == 0) base = atomicAdd(&B.ctrl[kCtrlClaim], 64u);
+    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+    if (base >= end) break;
+    const uint32_t i = base + (threadIdx.x & 63u);
+    const bool have = i < end;
+    V3 ro = {0, 0, 0}, rd = {0, 0, 1};
+    double weight = 0.0;
+    int depth = 1;
+    if (have) {
+      const WfNodeRay& r = B.rays[i - n_roots];
+      ro = {r.o[0], r.o[1], r.o[2]};
+      rd = {r.d[0], r.d[1], r.d[2]};
+      weight = r.weight;
+      depth = (int)r.depth;
+    }
+    QueueSink sink(B, n_roots);
+    trace_step<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, weight, depth, sink, c_primary, c_shadow,
+                                                    c_secondary, c_exact);
+    if (have) sink.store(B.outs[i]);
+  }
+  add_counters(B.counters, c_primary, c_shadow, c_secondary, c_exact);
+}
+
+// The pixels of the pass's tiles from the node records: depth-first walk, terms added in the order
+// of the one-lane evaluation (a node's untraced refraction and reflection, its own term, then the
+// reflected subtree, then the refracted one), and the framebuffer store (src/graphics.rs:44-46, 59-74).
+__global__ void __launch_bounds__(kBlock) wf_gather_kernel(DevScene S, DevCamera C, RenderTarget T, uint32_t tile_base,
+                                                           const WfNodeOut* __restrict__ outs) {
+  __shared__ float s_rgb[768];
+  __shared__ uint32_t s_px[256];
+  const V3 ambient = ld3(S.ambient);
+  V3 color = {0, 0, 0};
+  uint32_t pending[2 * kMaxDepth + 2];
+  int sp = 0;
+  pending[sp++] = blockIdx.x * kBlock + threadIdx.x;
+  while (sp > 0) {
+    const WfNodeOut& n = outs[pending[--sp]];
+    const uint32_t flags = n.flags;
+    if (flags & kUntracedRefraction) color = color + ambient * n.w_refraction;
+    if (flags & kUntracedReflection) color = color + ambient * n.w_reflection;
+    if (flags & kHasTerm) color = color + V3{n.t[0], n.t[1], n.t[2]};
+    const uint32_t refraction = n.child_refraction, reflection = n.child_reflection;
+    if (refraction != kNoNode) pending[sp++] = refraction;
+    if (reflection != kNoNode) pending[sp++] = reflection;  // on top: walked first
+  }
+  store_tile(C, T, tile_base + blockIdx.x, color, s_rgb, s_px);
+}
+
+// End of a launch: the rays counted by its passes join the frame's counters, unless the launch is
+// about to be rendered again by the depth-first kernel (which counts them itself).
+__global__ void __launch_bounds__(kCounterShards) wf_commit_kernel(const unsigned int* __restrict__ ctrl,
+                                                                   const DevCounters* __restrict__ mine, DevCounters* frame,
+                                                                   unsigned int* host_overflow) {
+  if (ctrl[kCtrlOverflow]) {
+    if (threadIdx.x == 0 && host_overflow) *host_overflow = 1u;  // the host reserves more room per pixel from now on
+    return;
+  }
+  const DevCounters c = mine[threadIdx.x];
+  DevCounters& f = frame[threadIdx.x];
+  f.rays_primary += c.rays_primary;
+  f.rays_shadow += c.rays_shadow;
+  f.rays_secondary += c.rays_secondary;
+  f.exact_tests += c.exact_tests;
+}
+
+// WIDE as in launch_render: scenes below this many spheres never take the sphere-per-lane sweep.
+constexpr uint32_t kWideSceneWf = 256;
+
+// Scenes whose sweeps walk a hierarchy of clusters: there a node is expensive, a deep pixel holds its
+// wavefront up for milliseconds, and the queue traffic (256 bytes per node) is small beside the
+// sweeps.  Scenes of a few dozen spheres are faster on the depth-first kernel (64 glass spheres at
+// 1080p: 1.2 ms against 1.6 ms).
+bool wavefront_applies(const DevScene& S) { return S.any_secondary && S.n_spheres >= kWideSceneWf && S.max_depth >= 2; }
+
+// ... and launches small enough for the depth-first kernel's last pixels to matter.  That kernel
+// spends a fixed time on its slowest pixels (about 5 ms with 157 clusters, 2.3 ms with 16) and then
+// 10-30 % less per pixel than the queue does, so from some launch size on it is the faster one:
+// measured cross-overs are 3.4 Mpixel for 1,000 spheres and 13 Mpixel for 10,000.
+bool wavefront_pays(const DevScene& S, uint64_t launch_pixels) {
+  return launch_pixels <= 2000000ull + 80000ull * (S.n_spheres_padded / kBundle);
+}
+
+namespace {
+
+template <bool WIDE, bool TRACK>
+hipError_t launch_primary_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, const DevCamera& C, const RenderTarget& T,
+                             const float4* prim, const float4* prim_cluster, uint32_t tile_base, const WavefrontBuffers& B) {
+  switch (lb) {
+    case 1: hipLaunchKernelGGL((wf_primary_kernel<1, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, prim, prim_cluster, tile_base, B); break;
+    case 2: hipLaunchKernelGGL((wf_primary_kernel<2, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, prim, prim_cluster, tile_base, B); break;
+    case 4: hipLaunchKernelGGL((wf_primary_kernel<4, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, prim, prim_cluster, tile_base, B); break;
+    default: hipLaunchKernelGGL((wf_primary_kernel<8, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, C, T, prim, prim_cluster, tile_base, B); break;
+  }
+  return hipGetLastError();
+}
+
+template <bool WIDE, bool TRACK>
+hipError_t launch_level_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, uint32_t level, uint32_t n_roots,
+                           const WavefrontBuffers& B) {
+  switch (lb) {
+    case 1: hipLaunchKernelGGL((wf_level_kernel<1, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    case 2: hipLaunchKernelGGL((wf_level_kernel<2, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    case 4: hipLaunchKernelGGL((wf_level_kernel<4, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    default: hipLaunchKernelGGL((wf_level_kernel<8, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
+                                   const float4* prim_cluster, const RenderTarget& T, const WavefrontBuffers& B,
+                                   DevCounters* counters) {
+  drop_stale_error();
+  if (T.n_local_tiles == 0) return hipSuccess;
+  const bool track = S.track_n1 != 0;
+  const int lb = light_batch_for(S.n_lights);
+  hipError_t e = hipMemsetAsync(B.ctrl, 0, sizeof(unsigned int) * kWavefrontCtrlWords, st);
+  if (e == hipSuccess) e = hipMemsetAsync(B.counters, 0, sizeof(DevCounters) * kCounterShards, st);
+  if (e != hipSuccess) return e;
+  // tiles per pass: their camera rays and nodes_per_pixel - 1 children per pixel must fit
+  const uint32_t pass_tiles = std::max<uint32_t>(1u, B.cap_nodes / (kBlock * std::max(1u, B.nodes_per_pixel)));
+  for (uint32_t tile_base = 0; tile_base < T.n_local_tiles; tile_base += pass_tiles) {
+    const uint32_t n_tiles = std::min(pass_tiles, T.n_local_tiles - tile_base);
+    const uint32_t n_roots = n_tiles * kBlock;
+    hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(64), 0, st, B.ctrl, 0u, B.cap_nodes, n_roots);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const dim3 grid(n_tiles);
+    e = track ? launch_primary_lb<true, true>(lb, grid, st, S, C, T, prim, prim_cluster, tile_base, B)
+              : launch_primary_lb<true, false>(lb, grid, st, S, C, T, prim, prim_cluster, tile_base, B);
+    if (e != hipSuccess) return e;
+    // levels 1 .. max_depth - 1 (nodes at depth max_depth are not traced: their parents account for them);
+    // enough resident workgroups to fill the GPU, no more than the pass could ever need
+    const dim3 level_grid(std::min<uint32_t>(1024u, std::max<uint32_t>(1u, n_tiles * 2u)));
+    for (uint32_t level = 1; level < S.max_depth; ++level) {
+      hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(64), 0, st, B.ctrl, level, B.cap_nodes, 0u);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+      e = track ? launch_level_lb<true, true>(lb, level_grid, st, S, level, n_roots, B)
+                : launch_level_lb<true, false>(lb, level_grid, st, S, level, n_roots, B);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(wf_gather_kernel, grid, dim3(kBlock), 0, st, S, C, T, tile_base, B.outs);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(wf_commit_kernel, dim3(1), dim3(kCounterShards), 0, st, B.ctrl, B.counters, counters, B.host_overflow);
+  return hipGetLastError();
+}
+
+const unsigned int* wavefront_overflow_flag(const WavefrontBuffers& B) { return B.ctrl + kCtrlOverflow; }
+
+}  // namespace rtk

@@ -168,6 +168,11 @@ class Device:
                 stream))
         return rgb, rgba
 
+    def set_trace_order(self, order, max_queue_nodes=0):
+        """How scenes with secondary rays are traced: abi.RTK_TRACE_AUTO / _DEPTH_FIRST / _BY_LEVEL, and
+        (when not 0) the capacity of the node queue of the level-by-level path."""
+        _check(library().rtk_set_trace_order(self.ctx, int(order), int(max_queue_nodes)))
+
     def render_device_bands(self, handle, camera, rank=0, world=1, band_tile_rows=1, first_tile_row=0, n_tile_rows=0,
                             compact=False, want_rgb=True, want_rgba8=True, out_rgb=None, out_rgba8=None):
         """One rank of a band partition (whole tile rows dealt round-robin in bands of `band_tile_rows`).

@@ -28,6 +28,9 @@
 
 namespace rtk {
 
+#ifndef RTK_WF_OCC
+#define RTK_WF_OCC 4
+#endif
 constexpr uint32_t kNoNode = 0xffffffffu;
 constexpr uint32_t kHasTerm = 1u, kUntracedRefraction = 2u, kUntracedReflection = 4u;
 
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(kBlock, 4) wf_primary_kernel(DevScene S, DevCa
 // wavefront (children of neighbouring parents, pushed side by side).  The claim counter may run past
 // the level's end by 64 per wavefront of the launch: far from wrapping for queues of up to 2^31 nodes.
 template <int LB, bool WIDE, bool TRACK>
-__global__ void __launch_bounds__(kBlock, 4) wf_level_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
+__global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_level_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
   const uint32_t end = B.ctrl[kCtrlLevelEnd + level];
   unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
   // wavefronts take 64 nodes at a time from the level's counter: nodes cost very different amounts

@@ -452,6 +452,151 @@ int rtk::flatten_scene(const rtk_scene* scene, rtk::FlatScene& out) {
   }
 }
 
+// The light grids of a scene whose lights all have w = 0 (LightGrid in rtk_device.h), one per light,
+// each built on a thread of its own.  keys: the spheres in sweep order; gd: per light the unit
+// direction and rho = -1/|L|.  False when a grid would not pay (lists too long, too many lights):
+// the scene then keeps the cluster sweeps for its shadow rays.
+struct LightGrids {
+  std::vector<rtk::LightGrid> header;
+  std::vector<uint2> cells;
+  std::vector<uint32_t> entries;
+};
+static bool build_light_grids(const SphereKey* keys, uint32_t n_sph, const double* center, const std::vector<double>& gd,
+                              uint32_t n_lights, LightGrids& out) {
+  if (n_lights == 0 || n_lights > 8u || n_sph == 0) return false;
+  // the spheres as the FP32 filter sees them: recentred, rounded, radius grown by the rounding
+  struct Disc {
+    double c[3], r;
+  };
+  std::vector<Disc> discs(n_sph);
+  double scale = 0.0;
+  for (uint32_t j = 0; j < n_sph; ++j) {
+    const double cd[3] = {keys[j].c[0] - center[0], keys[j].c[1] - center[1], keys[j].c[2] - center[2]};
+    const float cf[3] = {(float)cd[0], (float)cd[1], (float)cd[2]};
+    const double dx = cd[0] - cf[0], dy = cd[1] - cf[1], dz = cd[2] - cf[2];
+    const double R = keys[j].r * (1.0 + 1e-9) + std::sqrt(dx * dx + dy * dy + dz * dz) * 1.0001;
+    discs[j] = {{(double)cf[0], (double)cf[1], (double)cf[2]}, std::sqrt((double)round_up(R * R))};
+    scale = std::fmax(scale, std::sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]) + discs[j].r);
+  }
+  struct PerLight {
+    rtk::LightGrid header{};
+    std::vector<uint2> cells;
+    std::vector<uint32_t> entries;
+    bool ok = false;
+  };
+  std::vector<PerLight> per(n_lights);
+  auto build = [&](uint32_t k) {
+    PerLight& pl = per[k];
+    const double g[3] = {gd[4 * k], gd[4 * k + 1], gd[4 * k + 2]}, arho = std::fabs(gd[4 * k + 3]);
+    // basis of the plane perpendicular to g
+    int a = 0;
+    for (int i = 1; i < 3; ++i)
+      if (std::fabs(g[i]) < std::fabs(g[a])) a = i;
+    double ax[3] = {0, 0, 0};
+    ax[a] = 1.0;
+    double e1[3] = {ax[1] * g[2] - ax[2] * g[1], ax[2] * g[0] - ax[0] * g[2], ax[0] * g[1] - ax[1] * g[0]};
+    const double n1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    for (double& v : e1) v /= n1;
+    const double e2[3] = {g[1] * e1[2] - g[2] * e1[1], g[2] * e1[0] - g[0] * e1[2], g[0] * e1[1] - g[1] * e1[0]};
+    const float e1f[3] = {(float)e1[0], (float)e1[1], (float)e1[2]}, e2f[3] = {(float)e2[0], (float)e2[1], (float)e2[2]};
+    // every shading point on a sphere lies at or above the lowest point of the lowest sphere
+    double h_min = DBL_MAX;
+    for (const Disc& d : discs) h_min = std::fmin(h_min, d.c[0] * g[0] + d.c[1] * g[1] + d.c[2] * g[2] - d.r);
+    const double margin = 1e-4 * (1.0 + scale);
+    h_min -= 2.0 * margin;
+    // a sphere's shadow at height h has radius^2 = R^2 (1 + R^2 rho^2 + 2 |rho| (c.g - h)): widest at h_min
+    struct Shadow {
+      double u, v, r;
+    };
+    std::vector<Shadow> sh(n_sph);
+    double u0 = DBL_MAX, v0 = DBL_MAX, u1 = -DBL_MAX, v1 = -DBL_MAX, r_sum = 0.0;
+    for (uint32_t j = 0; j < n_sph; ++j) {
+      const Disc& d = discs[j];
+      const double h = d.c[0] * g[0] + d.c[1] * g[1] + d.c[2] * g[2];
+      const double r2 = d.r * d.r * (1.0 + d.r * d.r * arho * arho + 2.0 * arho * (h - h_min + d.r));
+      const double r = std::sqrt(r2) * (1.0 + 1e-4) + 1e-5 * (1.0 + scale);
+      // the device projects with the FP32 basis
+      const double u = d.c[0] * e1f[0] + d.c[1] * e1f[1] + d.c[2] * e1f[2], v = d.c[0] * e2f[0] + d.c[1] * e2f[1] + d.c[2] * e2f[2];
+      sh[j] = {u, v, r};
+      u0 = std::fmin(u0, u - r), u1 = std::fmax(u1, u + r), v0 = std::fmin(v0, v - r), v1 = std::fmax(v1, v + r);
+      r_sum += r;
+    }
+    if (!std::isfinite(u0) || !std::isfinite(u1) || !std::isfinite(v0) || !std::isfinite(v1) || !std::isfinite(r_sum)) return;
+    const double du = u1 - u0, dv = v1 - v0;
+    double cell = std::fmax(2.0 * r_sum / n_sph, std::sqrt(du * dv / (4.0 * n_sph)));
+    cell = std::fmax(cell, std::fmax(du, dv) / 4000.0);
+    if (!(cell > 0.0)) return;
+    // the cell index is formed in FP32 on the device: take u0, v0 and 1/cell as it will see them
+    const float u0f = (float)(u0 - 0.5 * cell), v0f = (float)(v0 - 0.5 * cell), inv = (float)(1.0 / cell);
+    const uint32_t nx = (uint32_t)((u1 - (double)u0f) * (double)inv) + 2u, ny = (uint32_t)((v1 - (double)v0f) * (double)inv) + 2u;
+    if (nx > 4096u || ny > 4096u) return;
+    auto range = [&](double lo, double hi, double origin, uint32_t n, uint32_t& i0, uint32_t& i1) {
+      // a hundredth of a cell either side covers the rounding of the device's index arithmetic
+      const double a0 = (lo - origin) * (double)inv - 0.01, a1 = (hi - origin) * (double)inv + 0.01;
+      i0 = a0 <= 0.0 ? 0u : std::min<uint32_t>((uint32_t)a0, n - 1u);
+      i1 = a1 <= 0.0 ? 0u : std::min<uint32_t>((uint32_t)a1, n - 1u);
+    };
+    pl.cells.assign((size_t)nx * ny, make_uint2(0u, 0u));
+    size_t total = 0;
+    for (uint32_t j = 0; j < n_sph; ++j) {
+      uint32_t i0, i1, j0, j1;
+      range(sh[j].u - sh[j].r, sh[j].u + sh[j].r, (double)u0f, nx, i0, i1);
+      range(sh[j].v - sh[j].r, sh[j].v + sh[j].r, (double)v0f, ny, j0, j1);
+      for (uint32_t y = j0; y <= j1; ++y)
+        for (uint32_t x = i0; x <= i1; ++x) ++pl.cells[(size_t)y * nx + x].y;
+      total += (size_t)(i1 - i0 + 1u) * (j1 - j0 + 1u);
+    }
+    if (total > (size_t)48u * n_sph) return;  // lists this long: the grid would not beat the cluster sweeps
+    uint32_t at = 0;
+    for (uint2& c : pl.cells) {
+      c.x = at;
+      at += c.y;
+      c.y = 0;
+    }
+    pl.entries.resize(total);
+    for (uint32_t j = 0; j < n_sph; ++j) {
+      uint32_t i0, i1, j0, j1;
+      range(sh[j].u - sh[j].r, sh[j].u + sh[j].r, (double)u0f, nx, i0, i1);
+      range(sh[j].v - sh[j].r, sh[j].v + sh[j].r, (double)v0f, ny, j0, j1);
+      for (uint32_t y = j0; y <= j1; ++y)
+        for (uint32_t x = i0; x <= i1; ++x) {
+          uint2& c = pl.cells[(size_t)y * nx + x];
+          pl.entries[c.x + c.y++] = j;
+        }
+    }
+    rtk::LightGrid& G = pl.header;
+    for (int i = 0; i < 3; ++i) G.e1[i] = e1f[i], G.e2[i] = e2f[i];
+    G.h_min = round_up(h_min + margin);  // the device's (p - centre).g is off by far less than the margin
+    G.u0 = u0f, G.v0 = v0f, G.inv_cell = inv;
+    G.nx = nx, G.ny = ny;
+    pl.ok = true;
+  };
+  {
+    std::vector<std::thread> pool;
+    pool.reserve(n_lights);
+    for (uint32_t k = 1; k < n_lights; ++k) {
+      try {
+        pool.emplace_back(build, k);
+      } catch (...) {  // no thread to be had: this light's grid is built here
+        build(k);
+      }
+    }
+    build(0);
+    for (std::thread& t : pool) t.join();
+  }
+  out.header.clear(), out.cells.clear(), out.entries.clear();
+  for (PerLight& pl : per) {
+    if (!pl.ok) return false;
+    pl.header.cell_base = (uint32_t)out.cells.size();
+    const uint32_t entry_base = (uint32_t)out.entries.size();
+    for (uint2& c : pl.cells) c.x += entry_base;
+    out.header.push_back(pl.header);
+    out.cells.insert(out.cells.end(), pl.cells.begin(), pl.cells.end());
+    out.entries.insert(out.entries.end(), pl.entries.begin(), pl.entries.end());
+  }
+  return true;
+}
+
 static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   if ((scene->n_objects && !scene->objects) || (scene->n_lights && !scene->lights))
     return fail(RTK_ERR_INVALID, "rtk_scene_upload: null object or light array");
@@ -619,6 +764,11 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   const uint32_t k_width = 4u;  // lights per table row and per sweep batch
   const bool tabulated = lights_uniform && n_pad;
   const uint32_t batches = (scene->n_lights + k_width - 1) / k_width;
+  // light grids for the shadow rays of incoherent shading points: only where rays recurse, the
+  // spheres are many enough for a cluster hierarchy, and every light has w = 0
+  LightGrids grids;
+  const bool shadow_grid = any_secondary && lights_uniform && n_sph >= 256u &&
+                           build_light_grids(keys.data(), n_sph, center, gd, scene->n_lights, grids);
 
   // One device allocation and one copy for all record arrays (each 256-byte aligned inside it):
   // the arrays are laid out first and then written where they will be copied from.  The
@@ -649,6 +799,19 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   const uint32_t n_supers = (n_clusters + kSuper - 1) / kSuper;
   const size_t at_super_ball = reserve(&rtk_scene_handle::d_super_ball, (size_t)n_supers * sizeof(float4));
   const size_t copied = total;
+  // built apart from the staged bytes (their size is not known when the staging is sized), copied behind them
+  const size_t extra_begin = total;
+  size_t at_light_grid = 0, at_grid_cells = 0, at_grid_entries = 0;
+  if (shadow_grid) {
+    at_light_grid = reserve(&rtk_scene_handle::d_light_grid, grids.header.size() * sizeof(rtk::LightGrid)) - extra_begin;
+    at_grid_cells = reserve(&rtk_scene_handle::d_grid_cells, grids.cells.size() * sizeof(uint2)) - extra_begin;
+    at_grid_entries = reserve(&rtk_scene_handle::d_grid_entries, grids.entries.size() * sizeof(uint32_t)) - extra_begin;
+    flat.extra.assign(total - extra_begin, 0);
+    std::memcpy(flat.extra.data() + at_light_grid, grids.header.data(), grids.header.size() * sizeof(rtk::LightGrid));
+    std::memcpy(flat.extra.data() + at_grid_cells, grids.cells.data(), grids.cells.size() * sizeof(uint2));
+    if (!grids.entries.empty())
+      std::memcpy(flat.extra.data() + at_grid_entries, grids.entries.data(), grids.entries.size() * sizeof(uint32_t));
+  }
   reserve(&rtk_scene_handle::d_prim, (size_t)n_pad * sizeof(float4));
   reserve(&rtk_scene_handle::d_prim_ball, (size_t)n_pad * sizeof(float4));
   reserve(&rtk_scene_handle::d_prim_cluster, n_pad ? (size_t)n_clusters_pad * sizeof(float4) : 0);
@@ -806,6 +969,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   d.lights_uniform = lights_uniform ? 1u : 0u;
   d.lights_bundled = lights_bundled ? 1u : 0u;
   d.k_width = k_width;
+  d.shadow_grid = shadow_grid ? 1u : 0u;
   d.n_objects = scene->n_objects;
   d.n_lights = scene->n_lights;
   d.n_spheres = n_sph;
@@ -832,6 +996,8 @@ int rtk::place_scene(rtk_context* ctx, const rtk::FlatScene& flat, rtk_scene_han
     e = hipMalloc(&h->d_block, flat.total);
     if (e == hipSuccess && flat.staged_bytes)
       e = hipMemcpy(h->d_block, flat.staged, flat.staged_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !flat.extra.empty())
+      e = hipMemcpy((unsigned char*)h->d_block + flat.staged_bytes, flat.extra.data(), flat.extra.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess)
       for (const rtk::FlatScene::Piece& p : flat.pieces) h->*(p.dst) = (unsigned char*)h->d_block + p.offset;
   }
@@ -856,6 +1022,9 @@ int rtk::place_scene(rtk_context* ctx, const rtk::FlatScene& flat, rtk_scene_han
   d.sph_ball = (decltype(d.sph_ball))h->d_sph_ball;
   d.cluster_ball = (decltype(d.cluster_ball))h->d_cluster_ball;
   d.super_ball = (decltype(d.super_ball))h->d_super_ball;
+  d.light_grid = (decltype(d.light_grid))h->d_light_grid;
+  d.grid_cells = (decltype(d.grid_cells))h->d_grid_cells;
+  d.grid_entries = (decltype(d.grid_entries))h->d_grid_entries;
   *out = h;
   return RTK_OK;
 }

@@ -75,6 +75,22 @@ struct DevLight {
 #define RTK_RO
 #endif
 
+// Shadow rays towards a light with w = 0 all run along one direction g, so "which spheres can
+// block this point" is a question about the point's projection along g: a grid over the plane
+// perpendicular to g, each cell listing the spheres whose shadow can reach some point above it.
+// (The shadow of a sphere widens away from the light -- the reference's shadow ray has a w
+// component, src/scene.rs:208-225 -- so the lists are built for points with (p - centre).g >= h_min,
+// where every shading point on a sphere lies; points below take the cluster sweeps.)
+struct LightGrid {
+  float e1[3], e2[3];        // orthonormal basis of the plane perpendicular to g
+  float h_min;
+  float u0, v0, inv_cell;    // cell (i, j) covers u0 + [i, i+1) / inv_cell, v0 + [j, j+1) / inv_cell
+  uint32_t nx, ny;
+  uint32_t cell_base;        // first cell of this light in DevScene::grid_cells
+  uint32_t reserved_[3];
+};
+static_assert(sizeof(LightGrid) == 64, "one light grid header is 64 bytes");
+
 struct DevScene {
   const RTK_RO DevObject* objects;
   const RTK_RO DevLight* lights;
@@ -91,6 +107,9 @@ struct DevScene {
   const RTK_RO float4* sph_ball;       // {cx, cy, cz, R'}: record of the wavefront-level test; padding has R' = -1e30
   const RTK_RO float4* cluster_ball;   // one ball around each aligned run of kBundle spheres; padded to kBundle with R = -1e30
   const RTK_RO float4* super_ball;     // one ball around each aligned run of kSuper clusters
+  const RTK_RO LightGrid* light_grid;  // per light, when shadow_grid
+  const RTK_RO uint2* grid_cells;      // {first entry, entries} per cell, the lights' grids one after the other
+  const RTK_RO uint32_t* grid_entries; // sweep positions of spheres
   uint32_t n_objects, n_lights, n_spheres, n_spheres_padded, n_planes;
   uint32_t n_clusters_padded;
   uint32_t n_spheres_grouped;  // n_spheres rounded up to kGroup: what the one-ray-per-lane sweeps cover
@@ -100,6 +119,7 @@ struct DevScene {
   uint32_t lights_uniform; // every light has w == 0: shadow-ray line directions do not depend on the shading point
   uint32_t lights_bundled; // every light has w == 0 or w == 1: the shadow rays of a patch form lines / cones
   uint32_t k_width;        // lights per k_table row (4 or 8)
+  uint32_t shadow_grid;    // the light grids exist (lights_uniform scenes with secondary rays and a cluster hierarchy)
   double center[3];      // recentring offset of the FP32 filter
   double ambient[3];
   float r2_max;          // max inflated squared radius

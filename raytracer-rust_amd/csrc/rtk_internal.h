@@ -45,6 +45,9 @@ struct rtk_scene_handle {
   void* d_sph_ball = nullptr;
   void* d_cluster_ball = nullptr;
   void* d_super_ball = nullptr;
+  void* d_light_grid = nullptr;
+  void* d_grid_cells = nullptr;
+  void* d_grid_entries = nullptr;
   void* d_prim_cluster = nullptr;  // camera-ray records of the cluster balls (rebuilt per camera)
   void* d_light_filter = nullptr;
   void* d_k_table = nullptr;
@@ -107,7 +110,8 @@ struct FlatScene {
   std::vector<Piece> pieces;
   unsigned char* staged = nullptr;  // the first `staged_bytes` bytes of the allocation
   size_t staged_bytes = 0;
-  size_t total = 0;                 // allocation size (the per-camera records follow the staged part)
+  std::vector<unsigned char> extra;  // bytes that follow the staged ones in the allocation, built apart from them
+  size_t total = 0;                 // allocation size (the per-camera records follow the staged part and the extra bytes)
   DevScene dev{};
   // Where the staged bytes live: memory from `grow` (e.g. a context's page-locked staging buffer,
   // which must hold at least the asked-for bytes until the scene has been placed), else `own`.

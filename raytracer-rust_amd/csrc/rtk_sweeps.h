@@ -239,8 +239,8 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
 // Lights are swept in batches of LB fused rays; the reference stops at the first blocked
 // light, so `n_rays` = index of the first blocked light + 1 (or the light count).
 template <int LB, bool WIDE>
-__device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3 p, unsigned& n_rays,
-                                              unsigned& n_exact) {
+__device__ __forceinline__ bool shadow_by_sweeps(const DevScene& S, bool active, V3 p, unsigned& n_rays,
+                                                 unsigned& n_exact) {
   bool in_shadow = false;
   unsigned rays = 0;
   bool need = active;
@@ -312,6 +312,104 @@ __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3
   }
   n_rays += rays;
   return in_shadow;
+}
+
+// The same through the light grids (LightGrid in rtk_device.h; scenes whose lights all have w = 0):
+// per light, the lane's point is projected along the light's direction, and the spheres listed in its
+// cell go through the per-ray FP32 filter and, if kept, the exact test -- a few dozen instructions
+// where the cluster sweep of 64 unrelated points costs thousands.  Lanes whose point lies below a
+// grid's floor (far-away points of a plane) take the cluster sweeps.
+template <int LB, bool WIDE>
+__device__ __forceinline__ bool shadow_by_grids(const DevScene& S, bool active, V3 p, unsigned& n_rays, unsigned& n_exact) {
+  const V3 pc = {p.x - S.center[0], p.y - S.center[1], p.z - S.center[2]};
+  const float px = (float)pc.x, py = (float)pc.y, pz = (float)pc.z;
+  bool in_range = active;
+  float rho_max = 0.0f;
+  for (uint32_t k = 0; k < S.n_lights; ++k) {
+    const float4 lf = S.light_filter[k];
+    const float h = __builtin_fmaf(pz, lf.z, __builtin_fmaf(py, lf.y, px * lf.x));
+    in_range = in_range && h >= S.light_grid[k].h_min;
+    rho_max = fmaxf(rho_max, fabsf(lf.w) * 1.0001f);
+  }
+  bool in_shadow = false;
+  unsigned rays = 0;
+  const bool swept = active && !in_range;
+  if (__any(swept)) {
+    unsigned swept_rays = 0;
+    const bool s = shadow_by_sweeps<LB, WIDE>(S, swept, p, swept_rays, n_exact);
+    if (swept) in_shadow = s, rays = swept_rays;
+  }
+  const float thr = filter_threshold(S, pc, rho_max);
+  bool need = in_range;
+  for (uint32_t k = 0; k < S.n_lights; ++k) {
+    if (!__any(need)) break;
+    const RTK_RO DevLight& L = S.lights[k];
+    bool blocked = false;
+    // the reference's shadow ray towards this light (src/scene.rs:208-225)
+    const V3 lv = ld3(L.pos) - p;
+    const double lw = L.pos[3] - 1.0;
+    const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+    const V3 d = {lv.x / m, lv.y / m, lv.z / m};
+    const double dw = lw / m;
+    if (need) {
+      ++rays;
+      for (uint32_t ip = 0; ip < S.n_planes; ++ip) {  // planes: exact
+        const RTK_RO DevObject& ob = S.objects[S.plane_object[ip]];
+        if (!plane_may_block(ob, L, p)) continue;
+        double t0, t1;
+        const int n = intersect_object(ob, p, d, dw, t0, t1);
+        if (n >= 1 && t0 > 0.0 && t0 < m) blocked = true;
+      }
+    }
+    const RTK_RO LightGrid& G = S.light_grid[k];
+    const float4 lf = S.light_filter[k];
+    uint32_t first = 0, count = 0;
+    if (need && !blocked) {
+      const float u = __builtin_fmaf(pz, G.e1[2], __builtin_fmaf(py, G.e1[1], px * G.e1[0]));
+      const float v = __builtin_fmaf(pz, G.e2[2], __builtin_fmaf(py, G.e2[1], px * G.e2[0]));
+      const float cu = (u - G.u0) * G.inv_cell, cv = (v - G.v0) * G.inv_cell;
+      // outside the grid no sphere's shadow reaches a point at or above the floor
+      if (cu >= 0.0f && cv >= 0.0f && cu < (float)G.nx && cv < (float)G.ny) {
+        const uint2 c = S.grid_cells[G.cell_base + (uint32_t)cv * G.nx + (uint32_t)cu];
+        first = c.x, count = c.y;
+      }
+    }
+    for (uint32_t base = 0; __any(base < count); base += 64u) {
+      // the per-ray filter over up to 64 listed spheres, then f64 on those it keeps
+      const uint32_t here = base < count ? min(count - base, 64u) : 0u;
+      unsigned long long kept = 0ull;
+      for (uint32_t e = 0; __any(e < here); ++e) {
+        if (e < here) {
+          const float4 c = S.sph_filter[S.grid_entries[first + base + e]];
+          const float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
+          const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+          const float cf = __builtin_fmaf(uu, kKappa, -c.w);
+          const float h = __builtin_fmaf(uz, lf.z, __builtin_fmaf(uy, lf.y, __builtin_fmaf(ux, lf.x, c.w * lf.w)));
+          if (__builtin_fmaf(h, h, -cf) >= thr) kept |= 1ull << e;
+        }
+      }
+      while (__any(kept != 0ull)) {
+        if (kept != 0ull) {
+          const uint32_t e = (uint32_t)__builtin_ctzll(kept);
+          kept &= kept - 1ull;
+          const RTK_RO SphRecord& rec = S.sph_record[S.grid_entries[first + base + e]];
+          double t0, t1;
+          const int n = intersect_sphere_record(S, rec, p, d, dw, t0, t1);
+          ++n_exact;
+          if (n == 2 && ((t0 > 0.0 && t0 < m) || (t1 > 0.0 && t1 < m))) blocked = true, kept = 0ull, count = 0u;
+        }
+      }
+    }
+    if (need && blocked) in_shadow = true, need = false;
+  }
+  n_rays += rays;
+  return in_shadow;
+}
+
+template <int LB, bool WIDE>
+__device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3 p, unsigned& n_rays, unsigned& n_exact) {
+  if (WIDE && S.shadow_grid) return shadow_by_grids<LB, WIDE>(S, active, p, n_rays, n_exact);
+  return shadow_by_sweeps<LB, WIDE>(S, active, p, n_rays, n_exact);
 }
 
 // ------------------------------------------------------------------------------------

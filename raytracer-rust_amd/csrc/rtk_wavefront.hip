@@ -227,11 +227,12 @@ constexpr uint32_t kWideSceneWf = 256;
 bool wavefront_applies(const DevScene& S) { return S.any_secondary && S.n_spheres >= kWideSceneWf && S.max_depth >= 2; }
 
 // ... and launches small enough for the depth-first kernel's last pixels to matter.  That kernel
-// spends a fixed time on its slowest pixels (about 5 ms with 157 clusters, 2.3 ms with 16) and then
-// 10-30 % less per pixel than the queue does, so from some launch size on it is the faster one:
-// measured cross-overs are 3.4 Mpixel for 1,000 spheres and 13 Mpixel for 10,000.
+// spends a fixed time on its slowest pixels (about 3 ms with 157 clusters, 1.5 ms with 16) and then
+// 20-50 % less per pixel than the queue does (which moves 256 bytes per node and cannot keep the
+// rays of one 8x8 patch together), so from some launch size on it is the faster one: measured
+// cross-overs are 1.7 Mpixel for 1,000 spheres and 5.9 Mpixel for 10,000.
 bool wavefront_pays(const DevScene& S, uint64_t launch_pixels) {
-  return launch_pixels <= 2000000ull + 80000ull * (S.n_spheres_padded / kBundle);
+  return launch_pixels <= 1200000ull + 30000ull * (S.n_spheres_padded / kBundle);
 }
 
 namespace {

@@ -1,6 +1,10 @@
 """Randomised parity sweep of the HIP path against the CPU oracle (run by hand on a GPU box):
 
-    python tests/fuzz_parity.py [n_scenes] [seed]          (FUZZ_BIG=1: thousands of spheres per scene)
+    python tests/fuzz_parity.py [n_scenes] [seed]          (FUZZ_BIG=1: thousands of spheres per scene;
+                                                            FUZZ_GLASS=1: hundreds to thousands of spheres, always
+                                                            glass, always w = 0 lights: the light grids and the
+                                                            level-by-level order, at frame sizes either side of
+                                                            the library's choice between the two orders)
 
 Scenes are drawn from wide ranges -- sphere radii over three decades, fields far from the origin,
 lights of every kind next to and far from the geometry, general affine transforms, every texture,
@@ -23,11 +27,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 def random_scene(rtk, rng):
     M, T = rtk.Matrix4x4, rtk.Texture
     scene = rtk.Scene()
-    n = int(rng.choice([2000, 5000, 12000] if os.environ.get("FUZZ_BIG") else [3, 20, 70, 200, 600]))
+    only_glass = bool(os.environ.get("FUZZ_GLASS"))
+    n = int(rng.choice([300, 700, 2500, 6000] if only_glass else [2000, 5000, 12000] if os.environ.get("FUZZ_BIG") else [3, 20, 70, 200, 600]))
     extent = float(10.0 ** rng.uniform(0.3, 2.5))
     offset = rng.normal(size=3) * float(rng.choice([0.0, 0.0, 10.0, 3000.0]))
     r_lo, r_hi = extent * 10.0 ** rng.uniform(-3.0, -1.5), extent * 10.0 ** rng.uniform(-1.3, -0.3)
-    glass = rng.random() < 0.3
+    glass = only_glass or rng.random() < 0.3
     mat = rtk.Material.default()
     for _ in range(int(rng.integers(0, 3))):
         t = M.translate(*(offset + rng.normal(size=3) * extent * 0.1))
@@ -54,7 +59,7 @@ def random_scene(rtk, rng):
             m = m.with_transparency(0.9).with_reflective(0.9).with_ambient(0.2).with_diffuse(0.2).with_refractivity(
                 float(rng.choice([1.0, 1.5])))
         scene.add_object(rtk.Sphere().with_material(m).with_transform(t))
-    kinds = rng.choice(["w0", "w1", "mixed", "exotic"], p=[0.4, 0.25, 0.25, 0.1])
+    kinds = "w0" if only_glass else rng.choice(["w0", "w1", "mixed", "exotic"], p=[0.4, 0.25, 0.25, 0.1])
     for k in range(int(rng.integers(1, 7))):
         near = rng.random() < 0.4
         pos = offset + (rng.normal(size=3) * extent * (0.3 if near else 3.0) + np.array([0, extent * (0.5 if near else 2.0), 0]))

@@ -81,6 +81,8 @@ def main():
     import oracle_binding as oracle
 
     dev = device.Device(0)
+    if os.environ.get("RTK_TRACE_ORDER"):  # 1: depth first, 2: level by level, whatever the library would pick
+        dev.set_trace_order(int(os.environ["RTK_TRACE_ORDER"]))
     bad = 0
     for seed in range(seed0, seed0 + n_scenes):
         rng = np.random.default_rng(seed)

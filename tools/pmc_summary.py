@@ -54,7 +54,7 @@ for name, counters in sorted(agg.items()):
         t64 = m.get("SQ_INSTS_VALU_TRANS_F64", 0)
         t32 = m.get("SQ_INSTS_VALU_TRANS_F32", 0)
         rest = m["SQ_INSTS_VALU"] - f64 - t64 - t32
-        d["f64_share_of_valu_insts"] = (f64 + t64) / m["SQ_INSTS_VALU"]
+        d["f64_share_of_valu_insts"] = (f64 + t64) / max(m["SQ_INSTS_VALU"], 1.0)  # a kernel that returns at once issues none
         if d.get("avg_ms") and d.get("valu_lane_util"):
             # flops actually executed: wave64 instructions x 64 lanes x share of lanes active (fma = 2)
             lanes = 64.0 * d["valu_lane_util"]

@@ -311,12 +311,16 @@ def main():
             out["roofline"]["gather_ms_last_frame"] = gather_ms
         if n_gpus == 1 and not args.no_extra:
             extra = {}
-            for name in ("C1", "C2", "C3"):
+            for name in ("C1", "C2", "C3", "C3_glass_1080p", "C4_glass_1080p"):
                 if name == args.workload:
                     continue
                 if name == "C1":  # the reference's bundled scene at its own resolution (src/main.rs:17-20)
                     s2 = rtk.PackedScene.from_yaml_file(os.path.join(ROOT, "tests", "golden", "test01.yaml")).build()
                     c2 = rtk.Camera(1920, 1080, rtk.PI / 3.0)
+                elif name.endswith("_glass_1080p"):  # a quarter of the spheres glass, reflective floor: secondary rays
+                    n2 = 1000 if name.startswith("C3") else 10000
+                    s2 = rtk.synthetic.make_scene(n2, True, 4, 0xC0FFEE00 + n2, glass=True)
+                    c2 = rtk.synthetic.make_camera(n2, 1920, 1080)
                 else:
                     s2, c2 = rtk.synthetic.config(name)
                 h2 = dev.upload(s2)

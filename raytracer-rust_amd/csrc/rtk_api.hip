@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -20,6 +21,8 @@
 #include <functional>
 #include <utility>
 #include <vector>
+
+#include <pthread.h>
 
 // The f64 matrix code below (cofactor inverse, look_at) must round like the reference's: no
 // fused multiply-adds, whatever the host architecture or -march offers.
@@ -369,6 +372,87 @@ void rtk_scene_release(rtk_context* ctx, rtk_scene_handle* h) {
   delete h;
 }
 
+// A few host threads kept for the library's data-parallel host work (flattening a scene).  Starting a
+// thread costs more than its share of flattening 10,000 objects does, so they are started once, on
+// first use, and parked on a condition variable in between; they are never joined (the object lives
+// until the process ends).  run(n, fn) calls fn(0) .. fn(n - 1), each once, on the parked threads
+// and the caller, and returns when all have returned; fn must not throw.  Jobs from several threads
+// take turns.  A forked child has none of the threads: there the caller does everything.
+class HostPool {
+ public:
+  static HostPool& get() {
+    static HostPool* pool = new HostPool();
+    return *pool;
+  }
+  uint32_t width() const { return n_workers_ + 1u; }
+  void run(uint32_t n, const std::function<void(uint32_t)>& fn) {
+    if (n == 0) return;
+    if (n == 1 || n_workers_ == 0) {
+      for (uint32_t i = 0; i < n; ++i) fn(i);
+      return;
+    }
+    std::lock_guard<std::mutex> one_job(run_mutex_);
+    {
+      std::lock_guard<std::mutex> lock(m_);
+      job_ = &fn;
+      job_n_ = n;
+      next_.store(0, std::memory_order_relaxed);
+      busy_ = n_workers_;
+      ++generation_;
+    }
+    wake_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lock(m_);
+    done_.wait(lock, [&] { return busy_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  HostPool() {
+    const uint32_t hw = std::thread::hardware_concurrency();
+    const uint32_t want = std::min(8u, hw ? hw : 1u) - 1u;
+    for (uint32_t t = 0; t < want; ++t) {
+      try {
+        std::thread([this] { worker(); }).detach();
+        ++n_workers_;
+      } catch (const std::system_error&) {
+        break;
+      }
+    }
+    (void)pthread_atfork(nullptr, nullptr, [] { HostPool::get().n_workers_ = 0; });
+  }
+  void work() {
+    for (;;) {
+      const uint32_t i = next_.fetch_add(1, std::memory_order_relaxed);
+      if (i >= job_n_) break;
+      (*job_)(i);
+    }
+  }
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lock(m_);
+        wake_.wait(lock, [&] { return generation_ != seen; });
+        seen = generation_;
+      }
+      work();
+      bool last;
+      {
+        std::lock_guard<std::mutex> lock(m_);
+        last = --busy_ == 0;
+      }
+      if (last) done_.notify_one();
+    }
+  }
+  std::mutex run_mutex_, m_;
+  std::condition_variable wake_, done_;
+  const std::function<void(uint32_t)>* job_ = nullptr;
+  uint32_t job_n_ = 0, busy_ = 0, n_workers_ = 0;
+  uint64_t generation_ = 0;
+  std::atomic<uint32_t> next_{0};
+};
+
 // A sphere on its way into sweep order: the bounding ball of its image and its object index.
 struct SphereKey {
   double c[3];
@@ -379,32 +463,49 @@ struct SphereKey {
 // Reorders the spheres so that every aligned run of kBundle is spatially compact: recursive
 // split along the longest axis of the centres' bounding box, the left part a multiple of
 // kBundle.  Which spheres end up in which run does not depend on how the work is scheduled (ties
-// by object index); the two halves of a large range are split on two threads.
-static void cluster_split(SphereKey* keys, uint32_t lo, uint32_t hi, int depth) {
+// by object index).  split_once does one split of [lo, hi) and returns where; cluster_split does
+// all of them below a range.
+static uint32_t split_once(SphereKey* keys, uint32_t lo, uint32_t hi) {
+  double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+  for (uint32_t i = lo; i < hi; ++i)
+    for (int a = 0; a < 3; ++a) mn[a] = std::fmin(mn[a], keys[i].c[a]), mx[a] = std::fmax(mx[a], keys[i].c[a]);
+  int axis = 0;
+  for (int a = 1; a < 3; ++a)
+    if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+  const uint32_t groups = (hi - lo + rtk::kBundle - 1) / rtk::kBundle;
+  const uint32_t mid = lo + (groups / 2) * rtk::kBundle;
+  std::nth_element(keys + lo, keys + mid, keys + hi, [axis](const SphereKey& p, const SphereKey& q) {
+    return p.c[axis] < q.c[axis] || (p.c[axis] == q.c[axis] && p.object < q.object);
+  });
+  return mid;
+}
+static void cluster_split(SphereKey* keys, uint32_t lo, uint32_t hi) {
   while (hi - lo > (uint32_t)rtk::kBundle) {
-    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-    for (uint32_t i = lo; i < hi; ++i)
-      for (int a = 0; a < 3; ++a) mn[a] = std::fmin(mn[a], keys[i].c[a]), mx[a] = std::fmax(mx[a], keys[i].c[a]);
-    int axis = 0;
-    for (int a = 1; a < 3; ++a)
-      if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
-    const uint32_t groups = (hi - lo + rtk::kBundle - 1) / rtk::kBundle;
-    const uint32_t mid = lo + (groups / 2) * rtk::kBundle;
-    std::nth_element(keys + lo, keys + mid, keys + hi, [axis](const SphereKey& p, const SphereKey& q) {
-      return p.c[axis] < q.c[axis] || (p.c[axis] == q.c[axis] && p.object < q.object);
-    });
-    if (depth < 3 && hi - lo >= 2048u) {
-      try {
-        std::thread left(cluster_split, keys, lo, mid, depth + 1);
-        cluster_split(keys, mid, hi, depth + 1);
-        left.join();
-        return;
-      } catch (const std::system_error&) {  // no thread to be had: both halves here
-      }
-    }
-    cluster_split(keys, lo, mid, depth + 1);
+    const uint32_t mid = split_once(keys, lo, hi);
+    cluster_split(keys, lo, mid);
     lo = mid;
   }
+}
+// The whole order: the first three levels of the split one level at a time (the ranges of a level are
+// independent), then the ranges left, each on one of the pool's threads.
+static void cluster_order(SphereKey* keys, uint32_t n) {
+  std::vector<std::pair<uint32_t, uint32_t>> ranges{{0u, n}};
+  if (n >= 4096u) {
+    for (int level = 0; level < 3; ++level) {
+      std::vector<uint32_t> mids(ranges.size());
+      HostPool::get().run((uint32_t)ranges.size(), [&](uint32_t r) {
+        mids[r] = ranges[r].second - ranges[r].first > (uint32_t)rtk::kBundle ? split_once(keys, ranges[r].first, ranges[r].second)
+                                                                              : ranges[r].second;
+      });
+      std::vector<std::pair<uint32_t, uint32_t>> next;
+      for (size_t r = 0; r < ranges.size(); ++r) {
+        next.push_back({ranges[r].first, mids[r]});
+        if (mids[r] < ranges[r].second) next.push_back({mids[r], ranges[r].second});
+      }
+      ranges.swap(next);
+    }
+  }
+  HostPool::get().run((uint32_t)ranges.size(), [&](uint32_t r) { cluster_split(keys, ranges[r].first, ranges[r].second); });
 }
 
 static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& out);
@@ -453,7 +554,7 @@ int rtk::flatten_scene(const rtk_scene* scene, rtk::FlatScene& out) {
 }
 
 // The light grids of a scene whose lights all have w = 0 (LightGrid in rtk_device.h), one per light,
-// each built on a thread of its own.  keys: the spheres in sweep order; gd: per light the unit
+// built side by side on the library's host threads.  keys: the spheres in sweep order; gd: per light the unit
 // direction and rho = -1/|L|.  False when a grid would not pay (lists too long, too many lights):
 // the scene then keeps the cluster sweeps for its shadow rays.
 struct LightGrids {
@@ -571,19 +672,13 @@ static bool build_light_grids(const SphereKey* keys, uint32_t n_sph, const doubl
     G.nx = nx, G.ny = ny;
     pl.ok = true;
   };
-  {
-    std::vector<std::thread> pool;
-    pool.reserve(n_lights);
-    for (uint32_t k = 1; k < n_lights; ++k) {
-      try {
-        pool.emplace_back(build, k);
-      } catch (...) {  // no thread to be had: this light's grid is built here
-        build(k);
-      }
+  HostPool::get().run(n_lights, [&](uint32_t k) {
+    try {
+      build(k);
+    } catch (const std::bad_alloc&) {
+      per[k].ok = false;
     }
-    build(0);
-    for (std::thread& t : pool) t.join();
-  }
+  });
   out.header.clear(), out.cells.clear(), out.entries.clear();
   for (PerLight& pl : per) {
     if (!pl.ok) return false;
@@ -627,7 +722,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   float r2_max = 0.f, r_max = 0.f, c_max = 0.f;
 
   // Per-object work (validation, the reference's cofactor inverse, bounding ball) is independent:
-  // large scenes split it over a few host threads.  Errors are reported for the lowest object index.
+  // it is split over the library's host threads.  Errors are reported for the lowest object index.
   if (any_pattern) pattern_inv.assign(12 * (size_t)scene->n_objects, 0.0);
   std::vector<double4> ball(scene->n_objects);
   struct Outcome {
@@ -686,25 +781,12 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
       if (src.kind == RTK_SPHERE) ball[i] = make_double4(t.at(0, 3), t.at(1, 3), t.at(2, 3), sigma_max3(t));
     }
   };
-  const uint32_t hw = std::thread::hardware_concurrency();
-  const uint32_t n_threads = scene->n_objects < 2048u ? 1u : std::max(1u, std::min({8u, hw ? hw : 1u, scene->n_objects / 1024u}));
-  std::vector<Outcome> outcomes(n_threads);
-  if (n_threads == 1) {
-    flatten(0, scene->n_objects, outcomes[0]);
-  } else {
-    std::vector<std::thread> pool;
-    const uint32_t chunk = (scene->n_objects + n_threads - 1) / n_threads;
-    pool.reserve(n_threads);
-    for (uint32_t t = 0; t < n_threads; ++t) {
-      const uint32_t begin = std::min(t * chunk, scene->n_objects), end_ = std::min((t + 1) * chunk, scene->n_objects);
-      try {
-        pool.emplace_back(flatten, begin, end_, std::ref(outcomes[t]));
-      } catch (...) {  // no thread to be had: this chunk runs here
-        flatten(begin, end_, outcomes[t]);
-      }
-    }
-    for (std::thread& t : pool) t.join();
-  }
+  // chunks of 512 objects, handed to the pool's threads as they come free
+  const uint32_t chunk = 512u, n_chunks = (scene->n_objects + chunk - 1u) / chunk;
+  std::vector<Outcome> outcomes(n_chunks);
+  HostPool::get().run(n_chunks, [&](uint32_t c) {
+    flatten(c * chunk, std::min((c + 1u) * chunk, scene->n_objects), outcomes[c]);
+  });
   for (const Outcome& oc : outcomes) {  // chunks are in object order: the first failure is the lowest index
     if (oc.status != RTK_OK) return fail(oc.status, oc.message);
     track_n1 = track_n1 || oc.track_n1;
@@ -723,7 +805,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   // members), so that the wavefront-level tests can skip whole clusters.  Closest-hit ties
   // are decided by object index (closest_consider), not by sweep order.
   const uint32_t n_sph = (uint32_t)keys.size();
-  cluster_split(keys.data(), 0u, n_sph, 0);
+  cluster_order(keys.data(), n_sph);
 
   // the FP32 records are recentred on the middle of the sphere centres' bounding box
   const uint32_t n_pad = round_up_to(n_sph, kBundle);
@@ -927,25 +1009,12 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   };
   for (uint32_t c = n_clusters; c < n_clusters_pad; ++c) cluster_ball[c] = make_float4(0.f, 0.f, 0.f, -1.0e30f);
   {
-    const uint32_t workers = n_clusters < 32u ? 1u : std::max(1u, std::min({8u, hw ? hw : 1u, n_clusters / 16u}));
-    std::vector<Maxima> maxima(workers);
-    std::vector<std::thread> pool;
-    pool.reserve(workers);
-    const uint32_t chunk = (n_clusters + workers - 1) / workers;
-    // the last cluster (the only one that may have empty slots, which read the last sphere's records) runs
-    // here, after the others
+    // runs of 8 clusters, handed to the pool's threads as they come free; the last cluster (the only
+    // one that may have empty slots, which read the last sphere's records) runs here, after the others
     const uint32_t n_parallel = n_clusters ? n_clusters - 1 : 0;
-    for (uint32_t t = 1; t < workers; ++t) {
-      const uint32_t begin = std::min(t * chunk, n_parallel), end_ = std::min((t + 1) * chunk, n_parallel);
-      if (begin == end_) continue;
-      try {
-        pool.emplace_back(cluster_records, begin, end_, std::ref(maxima[t]));
-      } catch (...) {  // no thread to be had: this chunk runs here
-        cluster_records(begin, end_, maxima[t]);
-      }
-    }
-    cluster_records(0, std::min(chunk, n_parallel), maxima[0]);
-    for (std::thread& t : pool) t.join();
+    const uint32_t run = 8u, n_runs = (n_parallel + run - 1u) / run;
+    std::vector<Maxima> maxima(std::max(1u, n_runs));
+    HostPool::get().run(n_runs, [&](uint32_t r) { cluster_records(r * run, std::min((r + 1u) * run, n_parallel), maxima[r]); });
     if (n_clusters) cluster_records(n_clusters - 1, n_clusters, maxima[0]);
     for (const Maxima& mx : maxima) r2_max = std::fmax(r2_max, mx.r2), r_max = std::fmax(r_max, mx.r), c_max = std::fmax(c_max, mx.c);
   }
@@ -987,13 +1056,27 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   return RTK_OK;
 }
 
-int rtk::place_scene(rtk_context* ctx, const rtk::FlatScene& flat, rtk_scene_handle** out) {
+int rtk::place_scene(rtk_context* ctx, const rtk::FlatScene& flat, rtk_scene_handle** out, rtk_scene_handle* reuse) {
   *out = nullptr;
-  rtk_scene_handle* h = new (std::nothrow) rtk_scene_handle();
-  if (!h) return fail(RTK_ERR_NOMEM, "rtk_scene_upload: out of host memory");
+  rtk_scene_handle* h = nullptr;
+  if (reuse && reuse->d_block && reuse->block_bytes >= flat.total) {
+    // the old scene's allocation is large enough: no hipFree / hipMalloc pair (a quarter of a millisecond)
+    void* const block = reuse->d_block;
+    const size_t bytes = reuse->block_bytes;
+    *reuse = rtk_scene_handle{};
+    reuse->d_block = block, reuse->block_bytes = bytes;
+    h = reuse;
+  } else {
+    if (reuse) rtk_scene_release(ctx, reuse);
+    h = new (std::nothrow) rtk_scene_handle();
+    if (!h) return fail(RTK_ERR_NOMEM, "rtk_scene_upload: out of host memory");
+  }
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess && flat.total) {
-    e = hipMalloc(&h->d_block, flat.total);
+    if (!h->d_block) {
+      e = hipMalloc(&h->d_block, flat.total);
+      if (e == hipSuccess) h->block_bytes = flat.total;
+    }
     if (e == hipSuccess && flat.staged_bytes)
       e = hipMemcpy(h->d_block, flat.staged, flat.staged_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess && !flat.extra.empty())
@@ -1603,23 +1686,50 @@ static int cached_scene(rtk_context* ctx, const rtk_scene* scene, rtk_scene_hand
     *out = ctx->cached_handle;
     return RTK_OK;
   }
-  if (ctx->cached_handle) {
-    // the previous frame of that scene was synchronised before rtk_render returned
-    rtk_scene_release(ctx, ctx->cached_handle);
-    ctx->cached_handle = nullptr;
-  }
-  rtk_scene_handle* h = nullptr;
-  const int rc = rtk_scene_upload(ctx, scene, &h);
-  if (rc != RTK_OK) return rc;
+  // A new scene.  The caller's arrays are copied for the next call's comparison on a thread of their
+  // own while this one flattens them; the device allocation of the previous scene is used again when
+  // it is large enough (its last frame was synchronised before rtk_render returned).
+  bool copied = true;
+  std::thread copier;
+  auto copy_scene = [&]() {
+    try {
+      ctx->cached_objects.assign(scene->objects, scene->objects + scene->n_objects);
+      ctx->cached_lights.assign(scene->lights, scene->lights + scene->n_lights);
+    } catch (const std::bad_alloc&) {
+      copied = false;
+    }
+  };
+  rtk_scene_handle* const previous = ctx->cached_handle;
+  ctx->cached_handle = nullptr;
   try {
-    ctx->cached_objects.assign(scene->objects, scene->objects + scene->n_objects);
-    ctx->cached_lights.assign(scene->lights, scene->lights + scene->n_lights);
-    ctx->cached_scene = *scene;
-    ctx->cached_handle = h;
-  } catch (const std::bad_alloc&) {
+    copier = std::thread(copy_scene);
+  } catch (const std::system_error&) {  // no thread to be had: copy here
+    copy_scene();
+  }
+  rtk::FlatScene flat;
+  flat.grow = context_staging;
+  flat.user = ctx;
+  rtk_scene_handle* h = nullptr;
+  int rc = rtk::flatten_scene(scene, flat);
+  if (rc == RTK_OK)
+    rc = rtk::place_scene(ctx, flat, &h, previous);
+  else if (previous)
+    rtk_scene_release(ctx, previous);
+  if (copier.joinable()) copier.join();
+  if (rc != RTK_OK) {
+    const std::string keep = rtk_last_error();
+    ctx->cached_objects.clear();
+    ctx->cached_lights.clear();
+    return fail(rc, keep);
+  }
+  if (!copied) {
     rtk_scene_release(ctx, h);
+    ctx->cached_objects.clear();
+    ctx->cached_lights.clear();
     return fail(RTK_ERR_NOMEM, "rtk_render: out of host memory");
   }
+  ctx->cached_scene = *scene;
+  ctx->cached_handle = h;
   *out = h;
   return RTK_OK;
 }

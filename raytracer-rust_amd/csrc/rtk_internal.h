@@ -31,6 +31,7 @@ int fail_hip(hipError_t e, const char* what);
 struct rtk_scene_handle {
   rtk::DevScene dev{};
   void* d_block = nullptr;  // the one device allocation every pointer below points into
+  size_t block_bytes = 0;   // its size
   void* d_objects = nullptr;
   void* d_lights = nullptr;
   void* d_filter = nullptr;
@@ -121,8 +122,10 @@ struct FlatScene {
 };
 // Validation and flattening (host work only); RTK_OK or an rtk_status with the error text set.
 int flatten_scene(const rtk_scene* scene, FlatScene& out);
-// Allocates on ctx's device, copies, and fills a new handle.
-int place_scene(rtk_context* ctx, const FlatScene& flat, rtk_scene_handle** out);
+// Allocates on ctx's device, copies, and fills a new handle.  With `reuse` (a handle of ctx that no
+// work in flight uses any more): its allocation takes the scene when it is large enough, and it is
+// released otherwise; either way `reuse` must not be used again.
+int place_scene(rtk_context* ctx, const FlatScene& flat, rtk_scene_handle** out, rtk_scene_handle* reuse = nullptr);
 
 // Which tiles of the frame a launch renders and where they go: the host-side form of RenderTarget.
 struct Partition {

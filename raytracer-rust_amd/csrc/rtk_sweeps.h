@@ -135,101 +135,101 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
     }
     const uint32_t super_end = min(super_first + kSuperSpheres, S.n_spheres_grouped);
     for (uint32_t first = super_first; wave_live && first < super_end; first += kBundle) {
-    bool reach = active;
-    if (cull) reach = active && may_reach(S.cluster_ball[first / kBundle]);
-    const unsigned long long reach_mask = __builtin_amdgcn_ballot_w64(reach);
-    if (reach_mask == 0ull) continue;
-    if (WIDE && __builtin_popcountll(reach_mask) <= kTransposeBelow && S.n_spheres_grouped - first >= 32u) {
-      // Few rays reach this cluster (incoherent rays): turn the loop around.  Every lane takes
-      // ONE sphere of the cluster; the reaching rays are broadcast one after the other and
-      // tested against all 64 spheres at once; each ray's owner keeps the set of spheres that
-      // passed and re-evaluates those per light before the f64 test.
-      const uint32_t lane = threadIdx.x & 63u;
-      const float4 mine = S.sph_filter[first + lane];       // padded to kBundle: always in range
-      const bool real = first + lane < S.n_spheres;         // padding repeats the last sphere
-      unsigned long long cand = 0ull;
-      for (unsigned long long rm = reach_mask; rm != 0ull; rm &= rm - 1ull) {
-        const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(rm));
-        const float qx = lane_value(px, src), qy = lane_value(py, src), qz = lane_value(pz, src);
-        const float qthr = lane_value(thr, src);
-        const float ux = qx - mine.x, uy = qy - mine.y, uz = qz - mine.z;
-        const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-        const float cf = __builtin_fmaf(uu, kKappa, -mine.w);
-        float m = -3.0e38f;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          const float h = __builtin_fmaf(uz, lane_value(gz[r], src),
-                                         __builtin_fmaf(uy, lane_value(gy[r], src),
-                                                        __builtin_fmaf(ux, lane_value(gx[r], src), mine.w * lane_value(rho[r], src))));
-          m = fmaxf(m, __builtin_fmaf(h, h, -cf));
-        }
-        const unsigned long long kept = __builtin_amdgcn_ballot_w64(real && m >= qthr);
-        if (lane == src) cand = kept;
-      }
-      // every lane now works through its own candidates; lanes run different spheres side by side
-      while (__any(cand != 0ull)) {
-        if (cand != 0ull) {
-          const uint32_t b = (uint32_t)__builtin_ctzll(cand);
-          cand &= cand - 1ull;
-          uint32_t mask = 1u;  // one ray per lane: the sphere passed that ray's test above
-          if (NR > 1) {        // several: which of them
-            const float4 c = S.sph_filter[first + b];
-            const float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
-            const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-            const float cf = __builtin_fmaf(uu, kKappa, -c.w);
-            mask = 0;
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-              const float h = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], __builtin_fmaf(ux, gx[r], c.w * rho[r])));
-              if (__builtin_fmaf(h, h, -cf) >= thr) mask |= 1u << r;
-            }
-          }
-          if (mask) exact(first + b, mask);
-          if (active && done()) active = false, cand = 0ull;
-        }
-      }
-      wave_live = __any(active);
-      continue;
-    }
-    const uint32_t end = min(first + (uint32_t)kBundle, S.n_spheres_grouped);
-    for (uint32_t j = first; j < end; j += kGroup) {
-      float4 q[kGroup];
-#pragma unroll
-      for (int g = 0; g < kGroup; ++g) q[g] = S.sph_filter[j + g];
-      float m = -3.0e38f;
-#pragma unroll
-      for (int g = 0; g < kGroup; ++g) {
-        float ux = px - q[g].x, uy = py - q[g].y, uz = pz - q[g].z;
-        float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-        float cf = __builtin_fmaf(uu, kKappa, -q[g].w);
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          float h = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], __builtin_fmaf(ux, gx[r], q[g].w * rho[r])));
-          m = fmaxf(m, __builtin_fmaf(h, h, -cf));
-        }
-      }
-      if (__any(reach && m >= thr)) {
-#pragma unroll 1
-        for (int g = 0; g < kGroup; ++g) {
-          float4 c = S.sph_filter[j + g];
-          float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
-          float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-          float cf = __builtin_fmaf(uu, kKappa, -c.w);
-          uint32_t mask = 0;
+      bool reach = active;
+      if (cull) reach = active && may_reach(S.cluster_ball[first / kBundle]);
+      const unsigned long long reach_mask = __builtin_amdgcn_ballot_w64(reach);
+      if (reach_mask == 0ull) continue;
+      if (WIDE && __builtin_popcountll(reach_mask) <= kTransposeBelow && S.n_spheres_grouped - first >= 32u) {
+        // Few rays reach this cluster (incoherent rays): turn the loop around.  Every lane takes
+        // ONE sphere of the cluster; the reaching rays are broadcast one after the other and
+        // tested against all 64 spheres at once; each ray's owner keeps the set of spheres that
+        // passed and re-evaluates those per light before the f64 test.
+        const uint32_t lane = threadIdx.x & 63u;
+        const float4 mine = S.sph_filter[first + lane];       // padded to kBundle: always in range
+        const bool real = first + lane < S.n_spheres;         // padding repeats the last sphere
+        unsigned long long cand = 0ull;
+        for (unsigned long long rm = reach_mask; rm != 0ull; rm &= rm - 1ull) {
+          const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(rm));
+          const float qx = lane_value(px, src), qy = lane_value(py, src), qz = lane_value(pz, src);
+          const float qthr = lane_value(thr, src);
+          const float ux = qx - mine.x, uy = qy - mine.y, uz = qz - mine.z;
+          const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+          const float cf = __builtin_fmaf(uu, kKappa, -mine.w);
+          float m = -3.0e38f;
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
-            float h = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], __builtin_fmaf(ux, gx[r], c.w * rho[r])));
-            if (__builtin_fmaf(h, h, -cf) >= thr) mask |= 1u << r;
+            const float h = __builtin_fmaf(uz, lane_value(gz[r], src),
+                                           __builtin_fmaf(uy, lane_value(gy[r], src),
+                                                          __builtin_fmaf(ux, lane_value(gx[r], src), mine.w * lane_value(rho[r], src))));
+            m = fmaxf(m, __builtin_fmaf(h, h, -cf));
           }
-          if (!reach) mask = 0;
-          if (mask) exact(j + g, mask);
+          const unsigned long long kept = __builtin_amdgcn_ballot_w64(real && m >= qthr);
+          if (lane == src) cand = kept;
         }
-        // lanes that need no further test drop out; the wavefront stops once all have
-        if (active && done()) active = false, reach = false;
+        // every lane now works through its own candidates; lanes run different spheres side by side
+        while (__any(cand != 0ull)) {
+          if (cand != 0ull) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            uint32_t mask = 1u;  // one ray per lane: the sphere passed that ray's test above
+            if (NR > 1) {        // several: which of them
+              const float4 c = S.sph_filter[first + b];
+              const float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
+              const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+              const float cf = __builtin_fmaf(uu, kKappa, -c.w);
+              mask = 0;
+#pragma unroll
+              for (int r = 0; r < NR; ++r) {
+                const float h = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], __builtin_fmaf(ux, gx[r], c.w * rho[r])));
+                if (__builtin_fmaf(h, h, -cf) >= thr) mask |= 1u << r;
+              }
+            }
+            if (mask) exact(first + b, mask);
+            if (active && done()) active = false, cand = 0ull;
+          }
+        }
         wave_live = __any(active);
-        if (!wave_live) break;
+        continue;
       }
-    }
+      const uint32_t end = min(first + (uint32_t)kBundle, S.n_spheres_grouped);
+      for (uint32_t j = first; j < end; j += kGroup) {
+        float4 q[kGroup];
+#pragma unroll
+        for (int g = 0; g < kGroup; ++g) q[g] = S.sph_filter[j + g];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int g = 0; g < kGroup; ++g) {
+          float ux = px - q[g].x, uy = py - q[g].y, uz = pz - q[g].z;
+          float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+          float cf = __builtin_fmaf(uu, kKappa, -q[g].w);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            float h = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], __builtin_fmaf(ux, gx[r], q[g].w * rho[r])));
+            m = fmaxf(m, __builtin_fmaf(h, h, -cf));
+          }
+        }
+        if (__any(reach && m >= thr)) {
+#pragma unroll 1
+          for (int g = 0; g < kGroup; ++g) {
+            float4 c = S.sph_filter[j + g];
+            float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
+            float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+            float cf = __builtin_fmaf(uu, kKappa, -c.w);
+            uint32_t mask = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+              float h = __builtin_fmaf(uz, gz[r], __builtin_fmaf(uy, gy[r], __builtin_fmaf(ux, gx[r], c.w * rho[r])));
+              if (__builtin_fmaf(h, h, -cf) >= thr) mask |= 1u << r;
+            }
+            if (!reach) mask = 0;
+            if (mask) exact(j + g, mask);
+          }
+          // lanes that need no further test drop out; the wavefront stops once all have
+          if (active && done()) active = false, reach = false;
+          wave_live = __any(active);
+          if (!wave_live) break;
+        }
+      }
     }
   }
 }

@@ -8,7 +8,7 @@ if os.environ.get("RTK_LIB"):  # A/B runs: another build of the library
     device.LIB_PATH = os.path.abspath(os.environ["RTK_LIB"])
 dev = device.Device(0)
 if os.environ.get("RTK_TRACE_ORDER"):  # 0 auto, 1 depth first, 2 by level
-    dev.set_trace_order(int(os.environ["RTK_TRACE_ORDER"]))
+    dev.set_trace_order(int(os.environ["RTK_TRACE_ORDER"]), int(os.environ.get("RTK_QUEUE_NODES", "0")))
 names = sys.argv[1:] or ["C2", "C3", "C4"]
 for name in names:
     size = (1920, 1080)

@@ -533,3 +533,50 @@ def test_host_render_into_pageable_and_pinned_buffers(rtk, dev, device_mod, name
     call(None, rgba3)  # and back
     assert np.array_equal(rgba3, want_rgba)
     handle.release()
+
+
+def test_scene_uploads_from_several_threads(rtk, device_mod):
+    """Scene flattening runs on a pool of host threads that the library keeps; uploads issued from
+    several caller threads at once (two contexts) take turns on it and must each produce the frame a
+    lone upload produces."""
+    import threading
+
+    import torch
+
+    scenes = [rtk.synthetic.make_scene(n, True, 3, 31 + n, glass=(n % 2 == 1)) for n in (2500, 3001, 4100, 2700)]
+    cameras = [rtk.synthetic.make_camera(n, 160, 90) for n in (2500, 3001, 4100, 2700)]
+    solo = device_mod.Device(0)
+    want = []
+    for scene, camera in zip(scenes, cameras):
+        h = solo.upload(scene)
+        rgb, rgba = solo.render_device(h, camera)
+        torch.cuda.synchronize()
+        want.append((rgb.clone(), rgba.clone()))
+        h.release()
+    devs = [device_mod.Device(0), device_mod.Device(0)]
+    got = [None] * len(scenes)
+    errors = []
+
+    def worker(which):
+        try:
+            for rep in range(3):
+                for i in range(which, len(scenes), 2):
+                    h = devs[which].upload(scenes[i])
+                    rgb, rgba = devs[which].render_device(h, cameras[i])
+                    devs[which].stats()  # waits for the frame
+                    got[i] = (rgb.clone(), rgba.clone())
+                    h.release()
+        except Exception as exc:  # pragma: no cover - reported below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for i in range(len(scenes)):
+        assert torch.equal(got[i][0], want[i][0]) and torch.equal(got[i][1], want[i][1]), i
+    for d in devs + [solo]:
+        d.close()

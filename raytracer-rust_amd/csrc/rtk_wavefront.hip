@@ -96,6 +96,95 @@ struct QueueSink {
   }
 };
 
+// The same sink for kernels whose workgroups move in step (one node per lane, then all together): a
+// node's children are parked in LDS, and when every wavefront of the workgroup has traced its node the
+// workgroup takes ONE run of queue positions for all of them -- the refracted children in thread
+// order, then the reflected ones.  Children of neighbouring parents so stay neighbours in the queue
+// whatever other workgroups push meanwhile, and the next level's wavefronts (64 consecutive entries
+// each) open few clusters.
+struct ParkedChild {
+  double o[3], d[3], weight;
+};
+struct ParkSink {
+  V3 t = {0, 0, 0};
+  double w_refraction = 0.0, w_reflection = 0.0;
+  uint32_t child_refraction = kNoNode, child_reflection = kNoNode, flags = 0;
+  bool parked_refraction = false, parked_reflection = false;
+  ParkedChild* park;  // LDS, [2][kBlock]: refracted, reflected
+
+  __device__ __forceinline__ explicit ParkSink(ParkedChild* lds) : park(lds) {}
+  __device__ __forceinline__ void term(V3 v, double w) {
+    t = v * w;
+    flags |= kHasTerm;
+  }
+  __device__ __forceinline__ void untraced_child(bool reflection, V3, double w) {
+    if (reflection)
+      w_reflection = w, flags |= kUntracedReflection;
+    else
+      w_refraction = w, flags |= kUntracedRefraction;
+  }
+  __device__ __forceinline__ void child(bool reflection, V3 o, V3 d, double w, int) {
+    ParkedChild& c = park[(reflection ? kBlock : 0) + threadIdx.x];
+    c.o[0] = o.x, c.o[1] = o.y, c.o[2] = o.z;
+    c.d[0] = d.x, c.d[1] = d.y, c.d[2] = d.z;
+    c.weight = w;
+    if (reflection)
+      parked_reflection = true;
+    else
+      parked_refraction = true;
+  }
+  // Every thread of the workgroup calls this once its node is traced.  s_counts: 10 words of LDS.
+  __device__ __forceinline__ void flush(const WavefrontBuffers& B, uint32_t n_roots, uint32_t child_depth, uint32_t* s_counts) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(parked_refraction), m1 = __builtin_amdgcn_ballot_w64(parked_reflection);
+    if (lane == 0) {
+      s_counts[wave] = (uint32_t)__builtin_popcountll(m0);
+      s_counts[4u + wave] = (uint32_t)__builtin_popcountll(m1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t total = 0;
+      for (int i = 0; i < 8; ++i) total += s_counts[i];
+      s_counts[8] = total ? atomicAdd(&B.ctrl[kCtrlNodes], total) : 0u;
+    }
+    __syncthreads();
+    uint32_t before0 = 0, before1 = 0;  // children of the workgroup queued ahead of this wavefront's, per kind
+    for (uint32_t w = 0; w < 4u; ++w) {
+      before1 += s_counts[w];
+      if (w < wave) before0 += s_counts[w], before1 += s_counts[4u + w];
+    }
+    const uint32_t base = s_counts[8];
+    auto place = [&](bool parked, unsigned long long m, uint32_t before, uint32_t slot, uint32_t& child) {
+      if (!parked) return;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      const uint32_t at = base + before + rank;
+      if (at < B.cap_nodes) {
+        const ParkedChild& c = park[slot + threadIdx.x];
+        WfNodeRay& r = B.rays[at - n_roots];
+        r.o[0] = c.o[0], r.o[1] = c.o[1], r.o[2] = c.o[2];
+        r.d[0] = c.d[0], r.d[1] = c.d[1], r.d[2] = c.d[2];
+        r.weight = c.weight;
+        r.depth = child_depth;
+        r.reserved_ = 0;
+        child = at;
+      } else {
+        B.ctrl[kCtrlOverflow] = 1u;
+      }
+    };
+    place(parked_refraction, m0, before0, 0u, child_refraction);
+    place(parked_reflection, m1, before1, kBlock, child_reflection);
+    __syncthreads();  // the parking slots and the counts are free again
+  }
+  __device__ __forceinline__ void store(WfNodeOut& out) const {
+    out.t[0] = t.x, out.t[1] = t.y, out.t[2] = t.z;
+    out.w_refraction = w_refraction;
+    out.w_reflection = w_reflection;
+    out.child_refraction = child_refraction;
+    out.child_reflection = child_reflection;
+    out.flags = flags;
+  }
+};
+
 __device__ __forceinline__ void add_counters(DevCounters* counters, unsigned c_primary, unsigned c_shadow, unsigned c_secondary,
                                              unsigned c_exact) {
   c_primary = wave_sum(c_primary);
@@ -135,41 +224,48 @@ __global__ void __launch_bounds__(kBlock, 4) wf_primary_kernel(DevScene S, DevCa
   const V3 origin = ld3(C.origin);
   const V3 dir = camera_ray_direction(C, x, y);
   unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
-  QueueSink sink(B, gridDim.x * kBlock);
+  __shared__ ParkedChild s_park[2 * kBlock];
+  __shared__ uint32_t s_counts[10];
+  ParkSink sink(s_park);
   trace_step<true, true, LB, WIDE, false, TRACK>(S, prim, prim_cluster, valid, true, origin, dir, 1.0, 0, sink, c_primary, c_shadow,
                                                  c_secondary, c_exact);
+  sink.flush(B, gridDim.x * kBlock, 1u, s_counts);
   sink.store(B.outs[blockIdx.x * kBlock + threadIdx.x]);
   add_counters(B.counters, c_primary, c_shadow, c_secondary, c_exact);
 }
 
-// Level l >= 1: the nodes queued by level l - 1, one lane per node, 64 consecutive queue entries per
-// wavefront (children of neighbouring parents, pushed side by side).  The claim counter may run past
-// the level's end by 64 per wavefront of the launch: far from wrapping for queues of up to 2^31 nodes.
+// Level l >= 1: the nodes queued by level l - 1 (all of depth l), one lane per node, 256 consecutive
+// queue entries per workgroup.  The claim counter may run past the level's end by 256 per workgroup of
+// the launch: far from wrapping for queues of up to 2^31 nodes.
 template <int LB, bool WIDE, bool TRACK>
 __global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_level_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
   const uint32_t end = B.ctrl[kCtrlLevelEnd + level];
   unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
-  // wavefronts take 64 nodes at a time from the level's counter: nodes cost very different amounts
+  __shared__ ParkedChild s_park[2 * kBlock];
+  __shared__ uint32_t s_counts[10];
+  __shared__ uint32_t s_base;
+  // workgroups take 256 nodes at a time from the level's counter (nodes cost very different amounts),
+  // one lane per node, and queue the children of the 256 together
   for (;;) {
-    unsigned int base = 0;
-    if ((threadIdx.x & 63u) == 0) base = atomicAdd(&B.ctrl[kCtrlClaim], 64u);
-    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+    if (threadIdx.x == 0) s_base = atomicAdd(&B.ctrl[kCtrlClaim], (unsigned int)kBlock);
+    __syncthreads();
+    const uint32_t base = s_base;
     if (base >= end) break;
-    const uint32_t i = base + (threadIdx.x & 63u);
+    const uint32_t i = base + threadIdx.x;
     const bool have = i < end;
     V3 ro = {0, 0, 0}, rd = {0, 0, 1};
     double weight = 0.0;
-    int depth = 1;
     if (have) {
       const WfNodeRay& r = B.rays[i - n_roots];
       ro = {r.o[0], r.o[1], r.o[2]};
       rd = {r.d[0], r.d[1], r.d[2]};
       weight = r.weight;
-      depth = (int)r.depth;
     }
-    QueueSink sink(B, n_roots);
-    trace_step<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, weight, depth, sink, c_primary, c_shadow,
-                                                    c_secondary, c_exact);
+    ParkSink sink(s_park);
+    if (__any(have))
+      trace_step<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, weight, (int)level, sink, c_primary,
+                                                      c_shadow, c_secondary, c_exact);
+    sink.flush(B, n_roots, level + 1u, s_counts);  // its barriers also keep s_base until every thread has read it
     if (have) sink.store(B.outs[i]);
   }
   add_counters(B.counters, c_primary, c_shadow, c_secondary, c_exact);
@@ -228,12 +324,10 @@ bool wavefront_applies(const DevScene& S) { return S.any_secondary && S.n_sphere
 
 // ... and launches small enough for the depth-first kernel's last pixels to matter.  That kernel
 // spends a fixed time on its slowest pixels (about 3 ms with 157 clusters, 1.5 ms with 16) and then
-// 20-50 % less per pixel than the queue does (which moves 256 bytes per node and cannot keep the
-// rays of one 8x8 patch together), so from some launch size on it is the faster one: measured
-// cross-overs are 1.7 Mpixel for 1,000 spheres and 5.9 Mpixel for 10,000.
-bool wavefront_pays(const DevScene& S, uint64_t launch_pixels) {
-  return launch_pixels <= 1200000ull + 30000ull * (S.n_spheres_padded / kBundle);
-}
+// about 20 % less per pixel than the queue does (which moves 256 bytes per node and makes the
+// wavefronts of a workgroup wait for each other), so from some launch size on it is the faster one:
+// the measured cross-overs are 7.6 Mpixel for 10,000 spheres and 7.4 Mpixel for 1,000.
+bool wavefront_pays(const DevScene&, uint64_t launch_pixels) { return launch_pixels <= 7500000ull; }
 
 namespace {
 

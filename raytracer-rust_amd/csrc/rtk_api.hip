@@ -1324,7 +1324,7 @@ static int frame_launch(Frame& f, const rtk::Partition& p, float* d_rgb_f32, uin
     RTK_HIP(rtk::launch_render_opaque(f.st, f.scene->dev, f.cam, f.scr.prim, f.scr.prim_ball, f.scr.prim_cluster, t,
                                       f.scr.opaque, f.scr.counters, split ? ctx->ev_rays[f.slot] : nullptr));
   } else {
-    RTK_HIP(rtk::launch_render(f.st, f.scene->dev, f.cam, t, f.scr.counters, f.scr.wavefront, f.scr.prim, f.scr.prim_cluster));
+    RTK_HIP(rtk::launch_render(f.st, f.scene->dev, f.cam, t, f.scr.counters, f.scr.wavefront, f.scr.prim, f.scr.prim_ball, f.scr.prim_cluster));
   }
   return RTK_OK;
 }

@@ -26,7 +26,8 @@ hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamer
 // with secondary rays and a depth limit of 2 or more is then traced level by level (the caller decides
 // whether that pays, see wavefront_applies / wavefront_pays); prim / prim_cluster are the per-camera records.
 hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const RenderTarget& T, DevCounters* counters,
-                         const WavefrontBuffers* wf = nullptr, const float4* prim = nullptr, const float4* prim_cluster = nullptr);
+                         const WavefrontBuffers* wf = nullptr, const float4* prim = nullptr, const float4* prim_ball = nullptr,
+                         const float4* prim_cluster = nullptr);
 
 // Level-by-level tracing (rtk_wavefront.hip).  wavefront_applies: the scene has secondary rays to
 // queue and enough objects for the cluster sweeps.  launch_render_wavefront renders the tiles of T
@@ -37,9 +38,15 @@ bool wavefront_applies(const DevScene& S);
 // ... and a launch of that many pixels is expected to finish sooner that way than depth first.
 bool wavefront_pays(const DevScene& S, uint64_t launch_pixels);
 hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
-                                   const float4* prim_cluster, const RenderTarget& T, const WavefrontBuffers& B,
-                                   DevCounters* counters);
+                                   const float4* prim_ball, const float4* prim_cluster, const RenderTarget& T,
+                                   const WavefrontBuffers& B, DevCounters* counters);
 const unsigned int* wavefront_overflow_flag(const WavefrontBuffers& B);
+// Level 0 of that order on the bundle tests of the opaque path (rtk_opaque.hip), for the scenes it
+// applies to: the camera rays of tiles [tile_base, tile_base + n_tiles) of T, records and children into B.
+bool queue_primary_bundled_applies(const DevScene& S);
+hipError_t launch_queue_primary_bundled(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
+                                        const float4* prim_ball, const float4* prim_cluster, const RenderTarget& T,
+                                        uint32_t tile_base, uint32_t n_tiles, const WavefrontBuffers& B);
 
 // Same for scenes without reflective or transparent materials: ray kernel(s) (camera +
 // shadow rays) and a shading kernel, with intermediate records in B.  `after_rays`, when not

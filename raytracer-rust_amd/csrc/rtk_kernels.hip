@@ -426,7 +426,7 @@ hipError_t launch_prep_primary(hipStream_t st, const DevScene& S, const DevCamer
 }
 
 hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, const RenderTarget& T, DevCounters* counters,
-                         const WavefrontBuffers* wf, const float4* prim, const float4* prim_cluster) {
+                         const WavefrontBuffers* wf, const float4* prim, const float4* prim_ball, const float4* prim_cluster) {
   drop_stale_error();
   if (T.n_local_tiles == 0) return hipSuccess;
   // TRACK kernels (some refractive index differs from the others) carry the entry before the winner
@@ -442,8 +442,8 @@ hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, 
   // Level by level where the scene has secondary rays to queue; the depth-first kernel below then
   // only runs (behind the flag) for a launch whose children did not fit the queue.
   const unsigned int* only_if = nullptr;  // (scenes of a handful of objects, above, are never queued)
-  if (wf && wf->cap_nodes >= kBlock * wf->nodes_per_pixel && prim && prim_cluster && S.any_secondary && S.max_depth >= 2) {
-    const hipError_t we = launch_render_wavefront(st, S, C, prim, prim_cluster, T, *wf, counters);
+  if (wf && wf->cap_nodes >= kBlock * wf->nodes_per_pixel && prim && prim_ball && prim_cluster && S.any_secondary && S.max_depth >= 2) {
+    const hipError_t we = launch_render_wavefront(st, S, C, prim, prim_ball, prim_cluster, T, *wf, counters);
     if (we != hipSuccess) return we;
     only_if = wavefront_overflow_flag(*wf);
   }

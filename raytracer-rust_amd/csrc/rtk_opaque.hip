@@ -41,6 +41,7 @@
 
 #include "rtk_shading.h"
 #include "rtk_sweeps.h"
+#include "rtk_queue.h"
 #include "rtk_kernels.h"
 
 #pragma clang fp contract(off)
@@ -710,6 +711,66 @@ __global__ void __launch_bounds__(kBlock, 5) render_uniform_kernel(DevScene S, D
     atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)rays);
     atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
   }
+}
+
+// Level 0 of the level-by-level order (rtk_wavefront.hip) on the bundle tests of the fused kernel:
+// the camera rays of the pass's tiles, their shadow rays and their shading exactly as above, but
+// the pixel is not stored -- what the camera ray's node adds to it goes to the node's record, and the
+// reflected and refracted children of the hit are queued.  For scenes whose lights all have w = 0
+// and whose refractive indices are all equal (n1 = 1 on every camera ray); one workgroup per tile,
+// node = workgroup * 256 + thread.  Three wavefronts per SIMD: the parked children take 28 KB of LDS
+// next to the 18 KB of hit geometry.
+template <int KW>
+__global__ void __launch_bounds__(kBlock, 3) queue_primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
+                                                                 const float4* __restrict__ prim_ball,
+                                                                 const float4* __restrict__ prim_cluster, RenderTarget T,
+                                                                 uint32_t tile_base, WavefrontBuffers B) {
+  __shared__ Stash stash;
+  __shared__ ParkedChild s_park[2 * kBlock];
+  __shared__ uint32_t s_counts[10];
+  const PixelRef px = pixel_ref(T, C, tile_base + blockIdx.x);
+  Closest best;
+  unsigned n_exact = 0;
+  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, n_exact, &stash);
+  const uint32_t obj = px.valid ? best.obj : 0xffffffffu;
+  const bool hit = obj != 0xffffffffu;
+  ParkSink sink(s_park);
+  V3 p = {0, 0, 0};
+  if (hit) {
+    const RTK_RO DevObject& ob = S.objects[obj];
+    const HitGeom g = lighting_data(ob, ld3(C.origin), get3(stash.dir), best.t);
+    put3(stash.over, g.over);
+    put3(stash.normal, g.normal);
+    p = g.over;
+    emit_children(S, ob, g, 1.0, 1.0, 0, sink);  // children first: nothing of them stays live across the shadow phase
+  }
+  unsigned rays = 0;
+  const bool in_shadow = shadow_phase_uniform<KW>(S, hit, p, rays, n_exact);
+  if (px.valid) {
+    if (hit)
+      sink.term(shade_hit_stashed(S, launder(obj), in_shadow, &stash), 1.0);
+    else
+      sink.term(ld3(S.ambient), 1.0);  // trace_inner: miss -> ambient_color
+  }
+  sink.flush(B, gridDim.x * kBlock, 1u, s_counts);
+  sink.store(B.outs[blockIdx.x * kBlock + threadIdx.x]);
+  const unsigned n_primary = wave_sum(px.valid ? 1u : 0u);
+  rays = wave_sum(rays);
+  n_exact = wave_sum(n_exact);
+  if ((threadIdx.x & 63u) == 0) {
+    atomicAdd(&counter_shard(B.counters)->rays_primary, (unsigned long long)n_primary);
+    atomicAdd(&counter_shard(B.counters)->rays_shadow, (unsigned long long)rays);
+    atomicAdd(&counter_shard(B.counters)->exact_tests, (unsigned long long)n_exact);
+  }
+}
+
+bool queue_primary_bundled_applies(const DevScene& S) { return S.lights_uniform && !S.track_n1 && S.max_depth >= 2; }
+
+hipError_t launch_queue_primary_bundled(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
+                                        const float4* prim_ball, const float4* prim_cluster, const RenderTarget& T,
+                                        uint32_t tile_base, uint32_t n_tiles, const WavefrontBuffers& B) {
+  hipLaunchKernelGGL((queue_primary_kernel<4>), dim3(n_tiles), dim3(kBlock), 0, st, S, C, prim, prim_ball, prim_cluster, T, tile_base, B);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------

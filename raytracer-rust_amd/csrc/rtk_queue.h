@@ -1,0 +1,111 @@
+// rtk_queue.h -- the node queue of the level-by-level order (rtk_wavefront.hip): control words,
+// record flags, and the sink through which a kernel that traces one node per lane hands the node's
+// terms and children on.  Device code only (included by .hip files after rtk_trace.h).
+#ifndef RTK_QUEUE_H
+#define RTK_QUEUE_H
+
+#include "rtk_trace.h"
+
+namespace rtk {
+
+constexpr uint32_t kNoNode = 0xffffffffu;
+constexpr uint32_t kHasTerm = 1u, kUntracedRefraction = 2u, kUntracedReflection = 4u;
+
+// words of the control block
+constexpr int kCtrlNodes = 0;     // nodes handed out so far in this pass (camera rays included)
+constexpr int kCtrlOverflow = 1;  // some child found no room: the launch is to be rendered again
+constexpr int kCtrlClaim = 2;     // next node of the current level no wavefront has taken yet
+constexpr int kCtrlLevelEnd = 3;  // [kCtrlLevelEnd + l]: one past the last node of level l
+
+// Result sink for one node of the level-by-level order: keeps the node's terms and queues its
+// children.  The workgroups of these kernels move in step (one node per lane, then all together): a
+// node's children are parked in LDS, and when every wavefront of the workgroup has traced its node
+// the workgroup takes ONE run of queue positions for all of them -- the refracted children in
+// thread order, then the reflected ones.  Children of neighbouring parents so stay neighbours in the
+// queue whatever other workgroups push meanwhile, and the next level's wavefronts (64 consecutive
+// entries each) open few clusters.
+struct ParkedChild {
+  double o[3], d[3], weight;
+};
+struct ParkSink {
+  V3 t = {0, 0, 0};
+  double w_refraction = 0.0, w_reflection = 0.0;
+  uint32_t child_refraction = kNoNode, child_reflection = kNoNode, flags = 0;
+  bool parked_refraction = false, parked_reflection = false;
+  ParkedChild* park;  // LDS, [2][kBlock]: refracted, reflected
+
+  __device__ __forceinline__ explicit ParkSink(ParkedChild* lds) : park(lds) {}
+  __device__ __forceinline__ void term(V3 v, double w) {
+    t = v * w;
+    flags |= kHasTerm;
+  }
+  __device__ __forceinline__ void untraced_child(bool reflection, V3, double w) {
+    if (reflection)
+      w_reflection = w, flags |= kUntracedReflection;
+    else
+      w_refraction = w, flags |= kUntracedRefraction;
+  }
+  __device__ __forceinline__ void child(bool reflection, V3 o, V3 d, double w, int) {
+    ParkedChild& c = park[(reflection ? kBlock : 0) + threadIdx.x];
+    c.o[0] = o.x, c.o[1] = o.y, c.o[2] = o.z;
+    c.d[0] = d.x, c.d[1] = d.y, c.d[2] = d.z;
+    c.weight = w;
+    if (reflection)
+      parked_reflection = true;
+    else
+      parked_refraction = true;
+  }
+  // Every thread of the workgroup calls this once its node is traced.  s_counts: 10 words of LDS.
+  __device__ __forceinline__ void flush(const WavefrontBuffers& B, uint32_t n_roots, uint32_t child_depth, uint32_t* s_counts) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(parked_refraction), m1 = __builtin_amdgcn_ballot_w64(parked_reflection);
+    if (lane == 0) {
+      s_counts[wave] = (uint32_t)__builtin_popcountll(m0);
+      s_counts[4u + wave] = (uint32_t)__builtin_popcountll(m1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t total = 0;
+      for (int i = 0; i < 8; ++i) total += s_counts[i];
+      s_counts[8] = total ? atomicAdd(&B.ctrl[kCtrlNodes], total) : 0u;
+    }
+    __syncthreads();
+    uint32_t before0 = 0, before1 = 0;  // children of the workgroup queued ahead of this wavefront's, per kind
+    for (uint32_t w = 0; w < 4u; ++w) {
+      before1 += s_counts[w];
+      if (w < wave) before0 += s_counts[w], before1 += s_counts[4u + w];
+    }
+    const uint32_t base = s_counts[8];
+    auto place = [&](bool parked, unsigned long long m, uint32_t before, uint32_t slot, uint32_t& child) {
+      if (!parked) return;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      const uint32_t at = base + before + rank;
+      if (at < B.cap_nodes) {
+        const ParkedChild& c = park[slot + threadIdx.x];
+        WfNodeRay& r = B.rays[at - n_roots];
+        r.o[0] = c.o[0], r.o[1] = c.o[1], r.o[2] = c.o[2];
+        r.d[0] = c.d[0], r.d[1] = c.d[1], r.d[2] = c.d[2];
+        r.weight = c.weight;
+        r.depth = child_depth;
+        r.reserved_ = 0;
+        child = at;
+      } else {
+        B.ctrl[kCtrlOverflow] = 1u;
+      }
+    };
+    place(parked_refraction, m0, before0, 0u, child_refraction);
+    place(parked_reflection, m1, before1, kBlock, child_reflection);
+    __syncthreads();  // the parking slots and the counts are free again
+  }
+  __device__ __forceinline__ void store(WfNodeOut& out) const {
+    out.t[0] = t.x, out.t[1] = t.y, out.t[2] = t.z;
+    out.w_refraction = w_refraction;
+    out.w_reflection = w_reflection;
+    out.child_refraction = child_refraction;
+    out.child_reflection = child_reflection;
+    out.flags = flags;
+  }
+};
+
+}  // namespace rtk
+#endif

@@ -118,6 +118,47 @@ __device__ __forceinline__ bool shadow_brute(const DevScene& S, bool active, V3 
   return false;
 }
 
+// The children of a hit: `reflected_color` and `refracted_color` (src/scene.rs:228-272) with the
+// Schlick reflectance where the material both reflects and transmits (src/scene.rs:191-204).  n1: the
+// refractive index on the ray's side of the surface.  A child that may still be traced goes to
+// sink.child (refraction first), one cut off by the depth limit to sink.untraced_child.
+template <typename Sink>
+__device__ __forceinline__ void emit_children(const DevScene& S, const RTK_RO DevObject& ob, const HitGeom& g, double n1, double weight,
+                                              int depth, Sink& sink) {
+  const double reflectivity = ob.reflectivity, transparency = ob.transparency;
+  const bool has_refl = !is_approx_zero(reflectivity);   // reflected_color early-out
+  const bool has_refr = !is_approx_zero(transparency);   // refracted_color early-out
+  if (!has_refl && !has_refr) return;
+  const V3 scene_ambient = ld3(S.ambient);
+  const double n2 = ob.refractivity;
+  const double cos_i = dot3(g.eye, g.normal);
+  double w_refl = weight * reflectivity, w_refr = weight * transparency;
+  if (reflectivity > 0.0 && transparency > 0.0) {
+    double reflectance = shlick(n1, n2, cos_i);
+    w_refl = weight * (reflectivity * reflectance);
+    w_refr = weight * (transparency * (1.0 - reflectance));
+  }
+  const bool child_traces = (uint32_t)(depth + 1) < S.max_depth;
+  if (has_refr) {  // src/scene.rs:244-272
+    double n_ratio = n1 / n2;
+    double sin_t2 = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
+    if (!(sin_t2 > 1.0)) {
+      double cos_t = sqrt(1.0 - sin_t2);
+      V3 dir = g.normal * (n_ratio + cos_i - cos_t) - g.eye * n_ratio;  // the reference's `+`
+      if (child_traces)
+        sink.child(false, g.under, dir, w_refr, depth + 1);
+      else
+        sink.untraced_child(false, scene_ambient, w_refr);  // trace_inner(depth >= MAX_DEPTH)
+    }
+  }
+  if (has_refl) {  // src/scene.rs:228-241
+    if (child_traces)
+      sink.child(true, g.over, g.reflect, w_refl, depth + 1);
+    else
+      sink.untraced_child(true, scene_ambient, w_refl);
+  }
+}
+
 // One node of the ray tree: `trace_inner` (src/scene.rs:141-153) for the ray (ro, rd) that enters the
 // pixel's colour with factor `weight`: closest hit, `apply_lighting` (src/scene.rs:172-205) with its
 // shadow rays, and the node's terms and children handed to `sink`.  camera_sweep: the ray is a camera
@@ -158,48 +199,19 @@ __device__ __forceinline__ void trace_step(const DevScene& S, const float4* __re
     tex = sample_texture_at(S, ob, obj, g.objp);
     if (SECONDARY) {
       // children first, so that nothing of them stays live across the shadow sweep
-      const double reflectivity = ob.reflectivity, transparency = ob.transparency;
-      const bool has_refl = !is_approx_zero(reflectivity);   // reflected_color early-out
-      const bool has_refr = !is_approx_zero(transparency);   // refracted_color early-out
-      if (has_refl || has_refr) {
-        double n2 = ob.refractivity;
-        // n1: material of the entry just before the hit in the sorted list, else 1.0.  When
-        // every refractivity in the scene is 1.0 (track_n1 == 0) that is 1.0 either way.
-        // Two roots that close make the reference's container list drop entries: then by the letter.
-        double n1 = 1.0;
-        if constexpr (TRACK) {
+      double n1 = 1.0;
+      if constexpr (TRACK) {
+        // n1: material of the entry just before the hit in the sorted list, else 1.0 (1.0 either way when
+        // every refractivity in the scene is 1.0, track_n1 == 0).  Two roots within 1e-5 of each other
+        // make the reference's container list drop entries: then by the letter.
+        if (!is_approx_zero(ob.reflectivity) || !is_approx_zero(ob.transparency)) {
           if (graze)
             n1 = literal_n1(S, ro, rd, obj, best.t);
           else if (best.prev_obj != 0xffffffffu)
             n1 = S.objects[best.prev_obj].refractivity;
         }
-        const double cos_i = dot3(eye, normal);
-        double w_refl = weight * reflectivity, w_refr = weight * transparency;
-        if (reflectivity > 0.0 && transparency > 0.0) {
-          double reflectance = shlick(n1, n2, cos_i);
-          w_refl = weight * (reflectivity * reflectance);
-          w_refr = weight * (transparency * (1.0 - reflectance));
-        }
-        const bool child_traces = (uint32_t)(depth + 1) < S.max_depth;
-        if (has_refr) {  // src/scene.rs:244-272
-          double n_ratio = n1 / n2;
-          double sin_t2 = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
-          if (!(sin_t2 > 1.0)) {
-            double cos_t = sqrt(1.0 - sin_t2);
-            V3 dir = normal * (n_ratio + cos_i - cos_t) - eye * n_ratio;  // the reference's `+`
-            if (child_traces)
-              sink.child(false, g.under, dir, w_refr, depth + 1);
-            else
-              sink.untraced_child(false, scene_ambient, w_refr);  // trace_inner(depth >= MAX_DEPTH)
-          }
-        }
-        if (has_refl) {  // src/scene.rs:228-241
-          if (child_traces)
-            sink.child(true, g.over, g.reflect, w_refl, depth + 1);
-          else
-            sink.untraced_child(true, scene_ambient, w_refl);
-        }
       }
+      emit_children(S, ob, g, n1, weight, depth, sink);
     }
   }
 

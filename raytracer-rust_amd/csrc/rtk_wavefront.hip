@@ -19,7 +19,7 @@
 // their camera rays and a generous number of children fit; should the children of a pass not fit
 // after all, a flag is raised, and the caller re-renders the launch with the depth-first kernel
 // (which needs no queue), guarded by that flag.
-#include "rtk_trace.h"
+#include "rtk_queue.h"
 #include "rtk_kernels.h"
 
 #include <algorithm>
@@ -31,159 +31,6 @@ namespace rtk {
 #ifndef RTK_WF_OCC
 #define RTK_WF_OCC 4
 #endif
-constexpr uint32_t kNoNode = 0xffffffffu;
-constexpr uint32_t kHasTerm = 1u, kUntracedRefraction = 2u, kUntracedReflection = 4u;
-
-// words of the control block
-constexpr int kCtrlNodes = 0;     // nodes handed out so far in this pass (camera rays included)
-constexpr int kCtrlOverflow = 1;  // some child found no room: the launch is to be rendered again
-constexpr int kCtrlClaim = 2;     // next node of the current level no wavefront has taken yet
-constexpr int kCtrlLevelEnd = 3;  // [kCtrlLevelEnd + l]: one past the last node of level l
-
-// Result sink of trace_step for one node: keeps the node's terms, appends its children to the queue.
-struct QueueSink {
-  V3 t = {0, 0, 0};
-  double w_refraction = 0.0, w_reflection = 0.0;
-  uint32_t child_refraction = kNoNode, child_reflection = kNoNode, flags = 0;
-  WfNodeRay* rays;
-  unsigned int* ctrl;
-  uint32_t n_roots, cap_nodes;
-
-  __device__ __forceinline__ QueueSink(const WavefrontBuffers& B, uint32_t roots)
-      : rays(B.rays), ctrl(B.ctrl), n_roots(roots), cap_nodes(B.cap_nodes) {}
-  __device__ __forceinline__ void term(V3 v, double w) {
-    t = v * w;
-    flags |= kHasTerm;
-  }
-  __device__ __forceinline__ void untraced_child(bool reflection, V3, double w) {
-    if (reflection)
-      w_reflection = w, flags |= kUntracedReflection;
-    else
-      w_refraction = w, flags |= kUntracedRefraction;
-  }
-  // One atomic per wavefront: the lanes that push a child here take consecutive queue positions.
-  __device__ __forceinline__ void child(bool reflection, V3 o, V3 d, double w, int depth) {
-    const unsigned long long pushing = __builtin_amdgcn_ballot_w64(true);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t leader = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(pushing));
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pushing >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushing, 0u));
-    unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(&ctrl[kCtrlNodes], (unsigned int)__builtin_popcountll(pushing));
-    base = (unsigned int)__builtin_amdgcn_readlane((int)base, (int)leader);
-    const uint32_t at = base + rank;
-    if (at < cap_nodes) {
-      WfNodeRay& r = rays[at - n_roots];
-      r.o[0] = o.x, r.o[1] = o.y, r.o[2] = o.z;
-      r.d[0] = d.x, r.d[1] = d.y, r.d[2] = d.z;
-      r.weight = w;
-      r.depth = (uint32_t)depth;
-      r.reserved_ = 0;
-      if (reflection)
-        child_reflection = at;
-      else
-        child_refraction = at;
-    } else {
-      ctrl[kCtrlOverflow] = 1u;
-    }
-  }
-  __device__ __forceinline__ void store(WfNodeOut& out) const {
-    out.t[0] = t.x, out.t[1] = t.y, out.t[2] = t.z;
-    out.w_refraction = w_refraction;
-    out.w_reflection = w_reflection;
-    out.child_refraction = child_refraction;
-    out.child_reflection = child_reflection;
-    out.flags = flags;
-  }
-};
-
-// The same sink for kernels whose workgroups move in step (one node per lane, then all together): a
-// node's children are parked in LDS, and when every wavefront of the workgroup has traced its node the
-// workgroup takes ONE run of queue positions for all of them -- the refracted children in thread
-// order, then the reflected ones.  Children of neighbouring parents so stay neighbours in the queue
-// whatever other workgroups push meanwhile, and the next level's wavefronts (64 consecutive entries
-// each) open few clusters.
-struct ParkedChild {
-  double o[3], d[3], weight;
-};
-struct ParkSink {
-  V3 t = {0, 0, 0};
-  double w_refraction = 0.0, w_reflection = 0.0;
-  uint32_t child_refraction = kNoNode, child_reflection = kNoNode, flags = 0;
-  bool parked_refraction = false, parked_reflection = false;
-  ParkedChild* park;  // LDS, [2][kBlock]: refracted, reflected
-
-  __device__ __forceinline__ explicit ParkSink(ParkedChild* lds) : park(lds) {}
-  __device__ __forceinline__ void term(V3 v, double w) {
-    t = v * w;
-    flags |= kHasTerm;
-  }
-  __device__ __forceinline__ void untraced_child(bool reflection, V3, double w) {
-    if (reflection)
-      w_reflection = w, flags |= kUntracedReflection;
-    else
-      w_refraction = w, flags |= kUntracedRefraction;
-  }
-  __device__ __forceinline__ void child(bool reflection, V3 o, V3 d, double w, int) {
-    ParkedChild& c = park[(reflection ? kBlock : 0) + threadIdx.x];
-    c.o[0] = o.x, c.o[1] = o.y, c.o[2] = o.z;
-    c.d[0] = d.x, c.d[1] = d.y, c.d[2] = d.z;
-    c.weight = w;
-    if (reflection)
-      parked_reflection = true;
-    else
-      parked_refraction = true;
-  }
-  // Every thread of the workgroup calls this once its node is traced.  s_counts: 10 words of LDS.
-  __device__ __forceinline__ void flush(const WavefrontBuffers& B, uint32_t n_roots, uint32_t child_depth, uint32_t* s_counts) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(parked_refraction), m1 = __builtin_amdgcn_ballot_w64(parked_reflection);
-    if (lane == 0) {
-      s_counts[wave] = (uint32_t)__builtin_popcountll(m0);
-      s_counts[4u + wave] = (uint32_t)__builtin_popcountll(m1);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t total = 0;
-      for (int i = 0; i < 8; ++i) total += s_counts[i];
-      s_counts[8] = total ? atomicAdd(&B.ctrl[kCtrlNodes], total) : 0u;
-    }
-    __syncthreads();
-    uint32_t before0 = 0, before1 = 0;  // children of the workgroup queued ahead of this wavefront's, per kind
-    for (uint32_t w = 0; w < 4u; ++w) {
-      before1 += s_counts[w];
-      if (w < wave) before0 += s_counts[w], before1 += s_counts[4u + w];
-    }
-    const uint32_t base = s_counts[8];
-    auto place = [&](bool parked, unsigned long long m, uint32_t before, uint32_t slot, uint32_t& child) {
-      if (!parked) return;
-      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      const uint32_t at = base + before + rank;
-      if (at < B.cap_nodes) {
-        const ParkedChild& c = park[slot + threadIdx.x];
-        WfNodeRay& r = B.rays[at - n_roots];
-        r.o[0] = c.o[0], r.o[1] = c.o[1], r.o[2] = c.o[2];
-        r.d[0] = c.d[0], r.d[1] = c.d[1], r.d[2] = c.d[2];
-        r.weight = c.weight;
-        r.depth = child_depth;
-        r.reserved_ = 0;
-        child = at;
-      } else {
-        B.ctrl[kCtrlOverflow] = 1u;
-      }
-    };
-    place(parked_refraction, m0, before0, 0u, child_refraction);
-    place(parked_reflection, m1, before1, kBlock, child_reflection);
-    __syncthreads();  // the parking slots and the counts are free again
-  }
-  __device__ __forceinline__ void store(WfNodeOut& out) const {
-    out.t[0] = t.x, out.t[1] = t.y, out.t[2] = t.z;
-    out.w_refraction = w_refraction;
-    out.w_reflection = w_reflection;
-    out.child_refraction = child_refraction;
-    out.child_reflection = child_reflection;
-    out.flags = flags;
-  }
-};
 
 __device__ __forceinline__ void add_counters(DevCounters* counters, unsigned c_primary, unsigned c_shadow, unsigned c_secondary,
                                              unsigned c_exact) {
@@ -324,10 +171,10 @@ bool wavefront_applies(const DevScene& S) { return S.any_secondary && S.n_sphere
 
 // ... and launches small enough for the depth-first kernel's last pixels to matter.  That kernel
 // spends a fixed time on its slowest pixels (about 3 ms with 157 clusters, 1.5 ms with 16) and then
-// about 20 % less per pixel than the queue does (which moves 256 bytes per node and makes the
+// 10-20 % less per pixel than the queue does (which moves 256 bytes per node and makes the
 // wavefronts of a workgroup wait for each other), so from some launch size on it is the faster one:
-// the measured cross-overs are 7.6 Mpixel for 10,000 spheres and 7.4 Mpixel for 1,000.
-bool wavefront_pays(const DevScene&, uint64_t launch_pixels) { return launch_pixels <= 7500000ull; }
+// the measured cross-overs are 10.4 Mpixel for 10,000 spheres and 9.4 Mpixel for 1,000.
+bool wavefront_pays(const DevScene&, uint64_t launch_pixels) { return launch_pixels <= 10000000ull; }
 
 namespace {
 
@@ -358,8 +205,8 @@ hipError_t launch_level_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S,
 }  // namespace
 
 hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
-                                   const float4* prim_cluster, const RenderTarget& T, const WavefrontBuffers& B,
-                                   DevCounters* counters) {
+                                   const float4* prim_ball, const float4* prim_cluster, const RenderTarget& T,
+                                   const WavefrontBuffers& B, DevCounters* counters) {
   drop_stale_error();
   if (T.n_local_tiles == 0) return hipSuccess;
   const bool track = S.track_n1 != 0;
@@ -375,8 +222,12 @@ hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevC
     hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(64), 0, st, B.ctrl, 0u, B.cap_nodes, n_roots);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const dim3 grid(n_tiles);
-    e = track ? launch_primary_lb<true, true>(lb, grid, st, S, C, T, prim, prim_cluster, tile_base, B)
-              : launch_primary_lb<true, false>(lb, grid, st, S, C, T, prim, prim_cluster, tile_base, B);
+    // the camera level: on the opaque path's bundle tests where they apply, else through trace_step
+    if (queue_primary_bundled_applies(S))
+      e = launch_queue_primary_bundled(st, S, C, prim, prim_ball, prim_cluster, T, tile_base, n_tiles, B);
+    else
+      e = track ? launch_primary_lb<true, true>(lb, grid, st, S, C, T, prim, prim_cluster, tile_base, B)
+                : launch_primary_lb<true, false>(lb, grid, st, S, C, T, prim, prim_cluster, tile_base, B);
     if (e != hipSuccess) return e;
     // levels 1 .. max_depth - 1 (nodes at depth max_depth are not traced: their parents account for them);
     // enough resident workgroups to fill the GPU, no more than the pass could ever need

@@ -160,21 +160,19 @@ __global__ void __launch_bounds__(kCounterShards) wf_commit_kernel(const unsigne
   f.exact_tests += c.exact_tests;
 }
 
-// WIDE as in launch_render: scenes below this many spheres never take the sphere-per-lane sweep.
-constexpr uint32_t kWideSceneWf = 256;
-
-// Scenes whose sweeps walk a hierarchy of clusters: there a node is expensive, a deep pixel holds its
-// wavefront up for milliseconds, and the queue traffic (256 bytes per node) is small beside the
-// sweeps.  Scenes of a few dozen spheres are faster on the depth-first kernel (64 glass spheres at
-// 1080p: 1.2 ms against 1.6 ms).
-bool wavefront_applies(const DevScene& S) { return S.any_secondary && S.n_spheres >= kWideSceneWf && S.max_depth >= 2; }
+// Scenes that are swept through clusters at all (a handful of objects are intersected one by one by a
+// kernel of their own) and whose rays recurse.
+bool wavefront_applies(const DevScene& S) { return S.any_secondary && S.n_objects > kBruteObjects && S.max_depth >= 2; }
 
 // ... and launches small enough for the depth-first kernel's last pixels to matter.  That kernel
-// spends a fixed time on its slowest pixels (about 3 ms with 157 clusters, 1.5 ms with 16) and then
-// 10-20 % less per pixel than the queue does (which moves 256 bytes per node and makes the
-// wavefronts of a workgroup wait for each other), so from some launch size on it is the faster one:
-// the measured cross-overs are 10.4 Mpixel for 10,000 spheres and 9.4 Mpixel for 1,000.
-bool wavefront_pays(const DevScene&, uint64_t launch_pixels) { return launch_pixels <= 10000000ull; }
+// spends a fixed time on its slowest pixels (about 3 ms with 157 clusters, 1.5 ms with 16, 0.5 ms with
+// one) and then 10-20 % less per pixel than the queue does (which moves 256 bytes per node and makes
+// the wavefronts of a workgroup wait for each other), so from some launch size on it is the faster
+// one: the measured cross-overs are 10.4 Mpixel for 10,000 spheres, 9.4 Mpixel for 1,000, and about
+// 5 Mpixel for 64.
+bool wavefront_pays(const DevScene& S, uint64_t launch_pixels) {
+  return launch_pixels <= (S.n_spheres >= 256u ? 10000000ull : 5000000ull);
+}
 
 namespace {
 

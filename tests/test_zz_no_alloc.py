@@ -43,7 +43,9 @@ def render_static(device_mod, dev, handle, camera, rank=0, world=1):
 
 
 def counts(st):
-    return (st.rays_primary, st.rays_shadow, st.rays_secondary, st.exact_tests)
+    # the rays are the reference's; how many exact tests it took to answer them depends on the filters of
+    # the path (the allocating entry point may trace ray trees level by level from a queue, this one never does)
+    return (st.rays_primary, st.rays_shadow, st.rays_secondary)
 
 
 def test_static_scratch_render_equals_the_allocating_one(rtk, dev, device_mod):

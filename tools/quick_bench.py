@@ -44,7 +44,7 @@ for name in names:
     elif name[0] == "g" and name[1:].isdigit():  # a small glass scene: that many spheres + plane, 2 lights, 1080p
         n = int(name[1:])
         scene = rtk.synthetic.make_scene(n, True, 2, 0xC0FFEE00 + n, glass=True)
-        camera = rtk.synthetic.make_camera(n, 1920, 1080)
+        camera = rtk.synthetic.make_camera(n, *size)
     elif name == "C5s":
         scene, camera = rtk.synthetic.config("C5", 4096, 4096)
     else:

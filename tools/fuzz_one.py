@@ -1,0 +1,25 @@
+"""One scene of tests/fuzz_parity.py (seed as argument) rendered on the device and by the CPU oracle:
+prints the pixels whose FP32 colours differ by more than 1e-6 relative."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import fuzz_parity
+rtk = importlib.import_module("raytracer-rust_amd")
+device = importlib.import_module("raytracer-rust_amd.device")
+import oracle_binding as oracle
+seed = int(sys.argv[1])
+scene, camera, what = fuzz_parity.random_scene(rtk, np.random.default_rng(seed))
+dev = device.Device(0)
+if os.environ.get("RTK_TRACE_ORDER"):
+    dev.set_trace_order(int(os.environ["RTK_TRACE_ORDER"]))
+canvas = dev.render(scene, camera)
+rgb, rgba, st = oracle.render(scene, camera, threads=16)
+with np.errstate(all="ignore"):
+    rel = np.abs(canvas.rgb.astype(np.float64) - rgb) / np.maximum(np.abs(rgb), 1e-3)
+    rel[np.isinf(canvas.rgb) & (canvas.rgb == rgb.astype(np.float32))] = 0.0  # beyond the FP32 range on both sides
+bad = np.argwhere(~(rel < 1e-6))
+print(what, "differing entries:", len(bad))
+for y, x, c in bad[:12]:
+    print(f"pixel ({x},{y}) channel {c}: device {canvas.rgb[y, x, c]!r} oracle {rgb[y, x, c]!r} rgba8 {canvas.rgba8[y, x]} / {rgba[y, x]}")

@@ -298,16 +298,6 @@ __device__ __forceinline__ uint32_t cast_u8(double c) {
   return (uint32_t)v;
 }
 
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-__device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-  return v;
-}
 __device__ __forceinline__ float wave_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 
 // value of lane `src` (wavefront-uniform index) in every lane, through an SGPR: no memory round trip
@@ -315,10 +305,36 @@ __device__ __forceinline__ float lane_value(float v, uint32_t src) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)src));
 }
 
+// Reductions over the 64 lanes of a wavefront on the data-parallel-primitive path of the vector ALU
+// (no LDS round trips): an inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), the row
+// totals carried into the rows above (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3),
+// and the total read from lane 63.  A lane with no source inside its row, or outside the enabled rows,
+// receives `identity`.  Every lane of the wavefront must be active; the result is wavefront-uniform.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_from(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROWS, 0xf, false);
+}
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_reduce(T value, T identity, Op op) {
+  static_assert(sizeof(T) == 4, "one dword per lane");
+  const int id = __builtin_bit_cast(int, identity);
+  auto step = [&](int moved) { value = op(value, __builtin_bit_cast(T, moved)); };
+  step(dpp_from<0x111, 0xf>(id, __builtin_bit_cast(int, value)));
+  step(dpp_from<0x112, 0xf>(id, __builtin_bit_cast(int, value)));
+  step(dpp_from<0x114, 0xf>(id, __builtin_bit_cast(int, value)));
+  step(dpp_from<0x118, 0xf>(id, __builtin_bit_cast(int, value)));
+  step(dpp_from<0x142, 0xa>(id, __builtin_bit_cast(int, value)));
+  step(dpp_from<0x143, 0xc>(id, __builtin_bit_cast(int, value)));
+  return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, value), 63));
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+  return wave_reduce(v, 0.0f, [](float a, float b) { return a + b; });
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+  return wave_reduce(v, -3.0e38f, [](float a, float b) { return fmaxf(a, b); });
+}
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+  return wave_reduce(v, 0u, [](unsigned a, unsigned b) { return a + b; });
 }
 
 

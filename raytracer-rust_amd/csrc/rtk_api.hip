@@ -703,11 +703,13 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   // place at its start, the smaller arrays are copied behind it once their sizes are known.
   bool any_pattern = false;
   for (uint32_t i = 0; i < scene->n_objects && !any_pattern; ++i) any_pattern = scene->objects[i].material.pattern_transformed != 0;
+  size_t n_planes_in = 0;
+  for (uint32_t i = 0; i < scene->n_objects; ++i) n_planes_in += scene->objects[i].kind == RTK_PLANE;
   const size_t n_all = scene->n_objects, n_padded = n_all + kBundle, n_l = scene->n_lights;
-  const size_t bound = 18 * 256 + n_all * sizeof(DevObject) + n_l * (sizeof(DevLight) + sizeof(float4) + sizeof(uint32_t)) +
+  const size_t bound = 20 * 256 + n_planes_in * n_l * sizeof(double2) + n_all * sizeof(DevObject) + n_l * (sizeof(DevLight) + sizeof(float4) + sizeof(uint32_t)) +
                        n_padded * (3 * sizeof(float4) + sizeof(uint32_t) + sizeof(SphRecord)) + n_all * (sizeof(double4) + sizeof(uint32_t)) +
                        (any_pattern ? n_all * 12 * sizeof(double) : 0) + ((n_l + 3) / 4) * n_padded * sizeof(float4) +
-                       2 * (n_padded / kBundle + kBundle) * sizeof(float4);
+                       2 * (n_padded / kBundle + kBundle) * sizeof(float4) + (n_padded / kBundle + kBundle) * sizeof(unsigned long long);
   if (flat.grow) {
     flat.staged = flat.grow(flat.user, bound);
   } else {
@@ -871,6 +873,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   const size_t at_sph_object = reserve(&rtk_scene_handle::d_sph_object, (size_t)n_pad * sizeof(uint32_t));
   const size_t at_sph_record = reserve(&rtk_scene_handle::d_sph_record, (size_t)n_pad * sizeof(SphRecord));
   const size_t at_plane_object = reserve(&rtk_scene_handle::d_plane_object, plane_object.size() * sizeof(uint32_t));
+  const size_t at_plane_light = reserve(&rtk_scene_handle::d_plane_light, plane_object.size() * scene->n_lights * sizeof(double2));
   const size_t at_pattern_inv = reserve(&rtk_scene_handle::d_pattern_inv, pattern_inv.size() * sizeof(double));
   const size_t at_light_filter = reserve(&rtk_scene_handle::d_light_filter, (size_t)scene->n_lights * sizeof(float4));
   const size_t at_light_kind = reserve(&rtk_scene_handle::d_light_kind, (size_t)scene->n_lights * sizeof(uint32_t));
@@ -878,6 +881,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   const size_t at_sph_tab = reserve(&rtk_scene_handle::d_sph_tab, tabulated ? (size_t)n_pad * sizeof(float4) : 0);
   const size_t at_sph_ball = reserve(&rtk_scene_handle::d_sph_ball, (size_t)n_pad * sizeof(float4));
   const size_t at_cluster_ball = reserve(&rtk_scene_handle::d_cluster_ball, n_pad ? (size_t)n_clusters_pad * sizeof(float4) : 0);
+  const size_t at_cluster_plain = reserve(&rtk_scene_handle::d_cluster_plain, n_pad ? (size_t)n_clusters_pad * sizeof(unsigned long long) : 0);
   const uint32_t n_supers = (n_clusters + kSuper - 1) / kSuper;
   const size_t at_super_ball = reserve(&rtk_scene_handle::d_super_ball, (size_t)n_supers * sizeof(float4));
   const size_t copied = total;
@@ -913,6 +917,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   float4* const sph_ball = reinterpret_cast<float4*>(base + at_sph_ball);
   float4* const cluster_ball = reinterpret_cast<float4*>(base + at_cluster_ball);
   float4* const super_ball = reinterpret_cast<float4*>(base + at_super_ball);
+  unsigned long long* const cluster_plain = reinterpret_cast<unsigned long long*>(base + at_cluster_plain);
   if (!plane_object.empty()) std::memcpy(base + at_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
   if (!pattern_inv.empty()) std::memcpy(base + at_pattern_inv, pattern_inv.data(), pattern_inv.size() * sizeof(double));
 
@@ -931,6 +936,18 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
     } else {
       light_kind[k] = 0u;
       light_filter[k] = make_float4((float)gd[4 * k], (float)gd[4 * k + 1], (float)gd[4 * k + 2], (float)gd[4 * k + 3]);
+    }
+  }
+
+  // plane_may_block's per-(plane, light) part: row 1 of the plane's inverse applied to (L.xyz, L.w - 1)
+  // and 1e-12 times the magnitudes of its terms (non-finite values make the test keep the pair)
+  double2* const plane_light = reinterpret_cast<double2*>(base + at_plane_light);
+  for (size_t ip = 0; ip < plane_object.size(); ++ip) {
+    const double* m = objects[plane_object[ip]].inv;
+    for (uint32_t k = 0; k < scene->n_lights; ++k) {
+      const double* L = scene->lights[k].position;
+      const double a = m[4] * L[0], b = m[5] * L[1], c = m[6] * L[2], d = m[7] * (L[3] - 1.0);
+      plane_light[ip * scene->n_lights + k] = make_double2(a + b + c + d, 1.0e-12 * (std::fabs(a) + std::fabs(b) + std::fabs(c) + std::fabs(d)));
     }
   }
 
@@ -995,6 +1012,15 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
         sph_ball[j] = make_float4(0.f, 0.f, 0.f, -1.0e30f);
         if (tabulated) tabulate(j);
       }
+      // members whose exact test is that of a sphere of one radius: what the kernels' "sphere behind the
+      // shadow ray" test may be applied to
+      unsigned long long plain = 0ull;
+      for (uint32_t j = j0; j < j0 + members; ++j) {
+        const SphRecord& r = sph_record[j];
+        if (r.diagonal && r.scale[0] == r.scale[1] && r.scale[1] == r.scale[2] && r.scale[0] != 0.0 && std::isfinite(r.scale[0]))
+          plain |= 1ull << (j - j0);
+      }
+      cluster_plain[c] = plain;
       // one ball per cluster, around the balls of its members
       double m[3] = {0, 0, 0};
       for (uint32_t j = j0; j < j0 + members; ++j) m[0] += sph_ball[j].x, m[1] += sph_ball[j].y, m[2] += sph_ball[j].z;
@@ -1007,7 +1033,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
       cluster_ball[c] = make_float4(mf[0], mf[1], mf[2], round_up(reach * (1.0 + 1e-7)));
     }
   };
-  for (uint32_t c = n_clusters; c < n_clusters_pad; ++c) cluster_ball[c] = make_float4(0.f, 0.f, 0.f, -1.0e30f);
+  for (uint32_t c = n_clusters; c < n_clusters_pad; ++c) cluster_ball[c] = make_float4(0.f, 0.f, 0.f, -1.0e30f), cluster_plain[c] = 0ull;
   {
     // runs of 8 clusters, handed to the pool's threads as they come free; the last cluster (the only
     // one that may have empty slots, which read the last sphere's records) runs here, after the others
@@ -1097,6 +1123,7 @@ int rtk::place_scene(rtk_context* ctx, const rtk::FlatScene& flat, rtk_scene_han
   d.sph_object = (decltype(d.sph_object))h->d_sph_object;
   d.sph_record = (decltype(d.sph_record))h->d_sph_record;
   d.plane_object = (decltype(d.plane_object))h->d_plane_object;
+  d.plane_light = (decltype(d.plane_light))h->d_plane_light;
   d.pattern_inv = (decltype(d.pattern_inv))h->d_pattern_inv;
   d.light_filter = (decltype(d.light_filter))h->d_light_filter;
   d.light_kind = (decltype(d.light_kind))h->d_light_kind;
@@ -1105,6 +1132,7 @@ int rtk::place_scene(rtk_context* ctx, const rtk::FlatScene& flat, rtk_scene_han
   d.sph_ball = (decltype(d.sph_ball))h->d_sph_ball;
   d.cluster_ball = (decltype(d.cluster_ball))h->d_cluster_ball;
   d.super_ball = (decltype(d.super_ball))h->d_super_ball;
+  d.cluster_plain = (decltype(d.cluster_plain))h->d_cluster_plain;
   d.light_grid = (decltype(d.light_grid))h->d_light_grid;
   d.grid_cells = (decltype(d.grid_cells))h->d_grid_cells;
   d.grid_entries = (decltype(d.grid_entries))h->d_grid_entries;

@@ -99,6 +99,7 @@ struct DevScene {
   const RTK_RO uint32_t* sph_object;   // filter record -> object index
   const RTK_RO SphRecord* sph_record;  // filter record -> what its exact test needs (padded like the filter records)
   const RTK_RO uint32_t* plane_object; // plane list -> object index
+  const RTK_RO double2* plane_light;   // [plane][light]: row 1 of the plane's inverse applied to (L.xyz, L.w - 1), and 1e-12 x the sum of that row's term magnitudes (plane_may_block)
   const RTK_RO double* pattern_inv;    // per object, rows 0..2 of the inverse pattern transform (12 f64); null when no pattern has one
   const RTK_RO float4* light_filter;   // per light: w = 0: unit line direction g = L/|L| and rho = -1/|L|; w = 1: position minus DevScene::center
   const RTK_RO uint32_t* light_kind;   // per light: 0 (w == 0), 1 (w == 1), 2 (anything else)
@@ -107,6 +108,7 @@ struct DevScene {
   const RTK_RO float4* sph_ball;       // {cx, cy, cz, R'}: record of the wavefront-level test; padding has R' = -1e30
   const RTK_RO float4* cluster_ball;   // one ball around each aligned run of kBundle spheres; padded to kBundle with R = -1e30
   const RTK_RO float4* super_ball;     // one ball around each aligned run of kSuper clusters
+  const RTK_RO unsigned long long* cluster_plain; // per cluster, bit i: member i is a sphere of one radius (its inverse is sigma * identity plus a translation)
   const RTK_RO LightGrid* light_grid;  // per light, when shadow_grid
   const RTK_RO uint2* grid_cells;      // {first entry, entries} per cell, the lights' grids one after the other
   const RTK_RO uint32_t* grid_entries; // sweep positions of spheres

@@ -39,6 +39,7 @@ struct rtk_scene_handle {
   void* d_sph_object = nullptr;
   void* d_sph_record = nullptr;
   void* d_plane_object = nullptr;
+  void* d_plane_light = nullptr;
   void* d_light_kind = nullptr;
   void* d_pattern_inv = nullptr;
   void* d_prim = nullptr;          // camera-ray filter records (rebuilt per camera)
@@ -46,6 +47,7 @@ struct rtk_scene_handle {
   void* d_sph_ball = nullptr;
   void* d_cluster_ball = nullptr;
   void* d_super_ball = nullptr;
+  void* d_cluster_plain = nullptr;
   void* d_light_grid = nullptr;
   void* d_grid_cells = nullptr;
   void* d_grid_entries = nullptr;

@@ -213,9 +213,10 @@ __device__ __forceinline__ bool shadow_ray_blocked(const RTK_RO DevObject& ob, c
   V3 lv = ld3(L.pos) - p;
   const double lw = L.pos[3] - 1.0;
   const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
-  const V3 d = {lv.x / m, lv.y / m, lv.z / m};
+  double dw;
+  const V3 d = divide_by_length(lv, lw, m, dw);
   double t0, t1;
-  const int n = intersect_object(ob, p, d, lw / m, t0, t1);
+  const int n = intersect_object(ob, p, d, dw, t0, t1);
   return (n >= 1 && t0 > 0.0 && t0 < m) || (n == 2 && t1 > 0.0 && t1 < m);
 }
 
@@ -224,9 +225,10 @@ __device__ __forceinline__ bool shadow_ray_blocked(const DevScene& S, const RTK_
   V3 lv = ld3(L.pos) - p;
   const double lw = L.pos[3] - 1.0;
   const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
-  const V3 d = {lv.x / m, lv.y / m, lv.z / m};
+  double dw;
+  const V3 d = divide_by_length(lv, lw, m, dw);
   double t0, t1;
-  const int n = intersect_sphere_record(S, rec, p, d, lw / m, t0, t1);
+  const int n = intersect_sphere_record(S, rec, p, d, dw, t0, t1);
   return n == 2 && ((t0 > 0.0 && t0 < m) || (t1 > 0.0 && t1 < m));
 }
 
@@ -244,6 +246,33 @@ struct PixelFilter {
   float P[KW];    // p.g_k
   float thrp;     // threshold; +3e38 when parked (nothing passes)
 };
+
+// A sphere BEHIND a shadow ray.  Most (pixel, sphere, light) triples the filter keeps are a sphere and a
+// point on its own lit side: the line through the point does cross the sphere -- at negative
+// parameters.  For a sphere of one radius R (inverse = sigma * identity plus a translation) the
+// reference's object-space ray from p towards a w = 0 light at L is sigma u + t sigma (L - u)/m with
+// u = p - centre (src/scene.rs:208-225, src/maths/rays.rs:31-41), so its quadratic
+// (src/scene/shapes/spheres.rs:18-35) has c = sigma^2 |u|^2 - 1 and b = 2 sigma^2 u.(L - u)/m
+// = 2 sigma^2 |L| (u.g + rho |u|^2)/m with g = L/|L|, rho = -1/|L|.  When the computed b and c are both
+// >= 0 no root is positive: the computed discriminant b*b - 4*a*c is at most fl(b*b), whose correctly
+// rounded square root is b itself, so sqrt(disc) <= b, both numerators -b -+ sqrt(disc) are <= 0, and
+// `t > 0` fails for both quotients (or they are NaN, a = 0); a negative discriminant gives no roots at
+// all.  The reference then finds the light unblocked by this sphere, and the exact test can be left out.
+// Both signs are certified in FP32, for the records {c32, R'} of the wavefront-level test (R' covers
+// the rounding of the centre) and u32 = f - c32 formed directly (the expanded form of the tabulated
+// filter loses the 1e-4 by which a shading point stands off its surface):
+//   outside:      |u32| (1 - 8 eps) - R' >= Q1
+//                                   since |u| - R >= |u32| - R' - dp, dp the rounding of the recentred point;
+//   moving away:  h_k - |rho_k| gap >= Q3,  gap >= |u32|^2 - R'^2
+//                                   since h is within dh of u32.g + rho R'^2, and u.g + rho |u|^2 >=
+//                                   u32.g + rho |u32|^2 - dd (1 + |rho| (2 |u32| + dd)) for dd = dp + the
+//                                   rounding of the centre.
+// Q1 and Q3 also hold the f64 rounding of the reference's own c and b (a few 1e-16 of the ABSOLUTE
+// coordinates' magnitudes, the recentring offset included) with a factor of several hundred to spare.
+// The margins are per-pixel quantities; the kernel uses their maxima over the wavefront.
+struct BehindMargins {
+  float q1, q3;
+};
 template <int KW>
 __device__ __forceinline__ void park(PixelFilter<KW>& f) {
   f.x = f.y = f.z = 0.0f;
@@ -251,8 +280,13 @@ __device__ __forceinline__ void park(PixelFilter<KW>& f) {
   for (int k = 0; k < KW; ++k) f.P[k] = 0.0f;
   f.thrp = 3.0e38f;
 }
+__device__ __forceinline__ float float_above(double v) {
+  float r = (float)v;
+  if ((double)r < v) r = nextafterf(r, INFINITY);
+  return nextafterf(r, INFINITY);
+}
 template <int KW>
-__device__ __forceinline__ void arm(PixelFilter<KW>& f, const DevScene& S, V3 p, uint32_t kb, uint32_t nb) {
+__device__ __forceinline__ void arm(PixelFilter<KW>& f, const DevScene& S, V3 p, uint32_t kb, uint32_t nb, BehindMargins& bm) {
   const V3 pc = {p.x - S.center[0], p.y - S.center[1], p.z - S.center[2]};
   f.x = (float)pc.x, f.y = (float)pc.y, f.z = (float)pc.z;
   float rho_max = 0.0f;
@@ -278,6 +312,17 @@ __device__ __forceinline__ void arm(PixelFilter<KW>& f, const DevScene& S, V3 p,
   float tf = (float)t;
   if ((double)tf > t) tf = nextafterf(tf, -INFINITY);
   f.thrp = nextafterf(tf, -INFINITY);
+  // margins of the behind test
+  const double e32 = (double)kEps32;
+  const double reach = pn * (1.0 + e32) + (double)S.c_max;  // >= |u32| for every sphere
+  const double absolute = reach + fabs(S.center[0]) + fabs(S.center[1]) + fabs(S.center[2]);  // >= |p| + |centre| in world coordinates
+  const double dp = pn * e32 * 1.0001;                   // rounding of the recentred point (as in filter_threshold)
+  const double dd = dp + e32 * (double)S.c_max * 1.01;   // ... and of a recentred centre
+  const double rho = (double)rho_max;
+  bm.q1 = float_above(dp * 1.01 + 1.0e-12 * (absolute + reach));
+  bm.q3 = float_above(dh * 1.01 + dd * (1.0 + rho * (2.0 * reach + dd)) * 1.01 +
+                      1.01 * e32 * (hmax + rho * (2.0 * reach * reach + (double)S.r2_max)) +
+                      1.0e-12 * reach * (1.0 + 2.0 * rho * absolute));
 }
 constexpr float kTwoKappa = 2.0f * kKappa;
 
@@ -323,17 +368,24 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
     uint32_t occl = 0;
     PixelFilter<KW> f;
     park(f);
+    BehindMargins bm = {0.0f, 0.0f};
     bool live = false;
     if (need) {
-      for (uint32_t r = 0; r < nb; ++r)
-        for (uint32_t ip = 0; ip < S.n_planes; ++ip)
-          if (plane_may_block(S.objects[S.plane_object[ip]], S.lights[kb + r], p) &&
-              shadow_ray_blocked(S.objects[S.plane_object[ip]], S.lights[kb + r], p))
+      for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
+        const RTK_RO DevObject& plane = S.objects[S.plane_object[ip]];
+        const PlaneSide side = plane_side(plane, p);
+        for (uint32_t r = 0; r < nb; ++r)
+          if (plane_may_block(side, S.plane_light[ip * S.n_lights + kb + r]) && shadow_ray_blocked(plane, S.lights[kb + r], p))
             occl |= 1u << r;
+      }
       live = !(occl & 1u);
-      if (live) arm(f, S, p, kb, nb);
+      if (live) arm(f, S, p, kb, nb, bm);
     }
     const RTK_RO float4* ktab = S.k_table + (size_t)batch * S.n_spheres_padded * KV;
+    // the margins of the behind test, over the live pixels of the wavefront (the last factor covers the
+    // FP32 roundings of X and of X + Q2)
+    const float Q1 = wave_max_f(bm.q1);
+    const float Q3 = wave_max_f(bm.q3);
 
     // bundle of the patch; the slack covers the FP32 rounding of points and centres
     const Ball ball = make_ball(live, f.x, f.y, f.z);
@@ -378,13 +430,21 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
         // level 1: this lane's sphere of the cluster
         const float4 rec = S.sph_ball[first + lane];
         unsigned long long m = __builtin_amdgcn_ballot_w64(lines_reach(rec, 0.0f, rec.w));
+        const unsigned long long plain = S.cluster_plain[first / kBundle];
         bool changed = false;
         // level 2: per-ray tabulated filter, then the exact test
         for (; m != 0ull; m &= m - 1ull) {
-          const uint32_t j = first + (uint32_t)__builtin_ctzll(m);
+          const uint32_t member = (uint32_t)__builtin_ctzll(m), j = first + member;
           const float4 c = S.sph_tab[j];
           const float pc = __builtin_fmaf(f.z, c.z, __builtin_fmaf(f.y, c.y, f.x * c.x));
           const float e = __builtin_fmaf(pc, kTwoKappa, -c.w);
+          // behind test (see BehindMargins): the point's distance from the centre against R', and an
+          // upper bound of |u32|^2 - R'^2
+          const float rj = lane_value(rec.w, member);
+          const float ux = f.x - c.x, uy = f.y - c.y, uz = f.z - c.z;
+          const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+          const bool outside = ((plain >> member) & 1ull) != 0ull && __builtin_fmaf(__builtin_amdgcn_sqrtf(uu), 1.0f - 8.0f * kEps32, -rj) >= Q1;
+          const float gap = __builtin_fmaf(uu, 1.0f + 8.0f * kEps32, -(rj * rj) * (1.0f - 1.0e-6f)) * (1.0f + 4.0f * kEps32);
           uint32_t mask = 0;
 #pragma unroll
           for (int v = 0; v < KV; ++v) {
@@ -392,7 +452,8 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float h = f.P[v * 4 + i] - (&row.x)[i];
-              if (__builtin_fmaf(h, h, e) >= f.thrp) mask |= 1u << (v * 4 + i);
+              const bool behind = outside && __builtin_fmaf(-lrho[v * 4 + i], gap, h) >= Q3;
+              if (__builtin_fmaf(h, h, e) >= f.thrp && !behind) mask |= 1u << (v * 4 + i);
             }
           }
           mask &= ~occl;
@@ -469,11 +530,13 @@ __device__ __forceinline__ bool shadow_phase_bundled(const DevScene& S, bool nee
     uint32_t occl = 0;
     bool live = false;
     if (need) {
-      for (uint32_t r = 0; r < nb; ++r)
-        for (uint32_t ip = 0; ip < S.n_planes; ++ip)
-          if (plane_may_block(S.objects[S.plane_object[ip]], S.lights[kb + r], p) &&
-              shadow_ray_blocked(S.objects[S.plane_object[ip]], S.lights[kb + r], p))
+      for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
+        const RTK_RO DevObject& plane = S.objects[S.plane_object[ip]];
+        const PlaneSide side = plane_side(plane, p);
+        for (uint32_t r = 0; r < nb; ++r)
+          if (plane_may_block(side, S.plane_light[ip * S.n_lights + kb + r]) && shadow_ray_blocked(plane, S.lights[kb + r], p))
             occl |= 1u << r;
+      }
       live = !(occl & 1u);
     }
     const V3 pc = {p.x - S.center[0], p.y - S.center[1], p.z - S.center[2]};

@@ -43,6 +43,57 @@ __device__ __forceinline__ V3 xform(P m, V3 v, double w) {
           m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * w};
 }
 
+// ------------------------------------------------------------------------------------
+// Several IEEE divisions by one divisor.  The compiler's f64 division scales both operands away from
+// the ends of the exponent range (v_div_scale), refines a hardware reciprocal of the divisor by two
+// Newton steps, forms q0 = n r and one correction q = q0 + (n - d q0) r (v_div_fmas), and patches the
+// special cases (v_div_fixup).  For operands well inside the exponent range nothing is scaled or
+// patched: the quotient is exactly the sequence below, and the refined reciprocal -- 9 of its 13
+// instructions, among them the quarter-rate v_rcp_f64 -- depends on the divisor alone.  The functions
+// below share it between the numerators when every operand is in that range and divide one by one
+// otherwise (zeros, infinities, NaNs, very small and very large values): bit for bit the quotients of
+// `/` either way.
+__device__ __forceinline__ bool div_plain(double x) { return fabs(x) >= 0x1p-400 && fabs(x) < 0x1p400; }
+__device__ __forceinline__ double refined_reciprocal(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double quotient(double n, double d, double r) {
+  const double q = n * r;
+  return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+// {n0 / d, n1 / d}
+__device__ __forceinline__ void divide2(double n0, double n1, double d, double& q0, double& q1) {
+  if (div_plain(d) && div_plain(n0) && div_plain(n1)) {
+    const double r = refined_reciprocal(d);
+    q0 = quotient(n0, d, r), q1 = quotient(n1, d, r);
+  } else {
+    q0 = n0 / d, q1 = n1 / d;
+  }
+}
+// v / m for m = the length of a vector v is a part of: |v.i| <= m (1 + a few ulp), so a lower bound on
+// the components and an upper bound on m keep every operand in range
+__device__ __forceinline__ V3 divide_by_length(V3 v, double m) {
+  if (fabs(v.x) >= 0x1p-400 && fabs(v.y) >= 0x1p-400 && fabs(v.z) >= 0x1p-400 && m < 0x1p400) {
+    const double r = refined_reciprocal(m);
+    return {quotient(v.x, m, r), quotient(v.y, m, r), quotient(v.z, m, r)};
+  }
+  return {v.x / m, v.y / m, v.z / m};
+}
+// ... and a fourth component w (|w| <= m as well; exactly zero for lights built from points)
+__device__ __forceinline__ V3 divide_by_length(V3 v, double w, double m, double& qw) {
+  if (fabs(v.x) >= 0x1p-400 && fabs(v.y) >= 0x1p-400 && fabs(v.z) >= 0x1p-400 && m < 0x1p400 && (w == 0.0 || fabs(w) >= 0x1p-400)) {
+    const double r = refined_reciprocal(m);
+    qw = w == 0.0 ? w : quotient(w, m, r);  // m > 0: a zero keeps its sign
+    return {quotient(v.x, m, r), quotient(v.y, m, r), quotient(v.z, m, r)};
+  }
+  qw = w / m;
+  return {v.x / m, v.y / m, v.z / m};
+}
+
 // `Sphere::intersect` (src/scene/shapes/spheres.rs:18-35) on an object-space ray: the unit-sphere
 // quadratic.  direction.w stays dw (row 3 of the transforms is 0 0 0 1) and takes part in `a`;
 // sphere_to_ray.w = 1 - 1 = 0.
@@ -53,8 +104,7 @@ __device__ __forceinline__ int unit_sphere_roots(V3 oo, V3 dd, double dw, double
   double disc = b * b - 4.0 * a * c;
   if (disc >= 0.0) {
     double s = sqrt(disc);
-    t0 = (-b - s) / (2.0 * a);
-    t1 = (-b + s) / (2.0 * a);
+    divide2(-b - s, -b + s, 2.0 * a, t0, t1);
     return 2;
   }
   return 0;
@@ -89,23 +139,37 @@ __device__ __forceinline__ int intersect_sphere_record(const DevScene& S, const 
   return unit_sphere_roots(oo, dd, dw, t0, t1);
 }
 
-// Can the reference's shadow ray from p towards light L meet the plane `ob` at a positive
-// parameter?  `Plane::intersect` (src/scene/shapes/planes.rs:22-28) returns
-// t = -o'.y / d'.y for the object-space origin o' and direction d' = inverse * (L - p)/m.
-// o'.y is formed here exactly as intersect_object forms it.  d'.y has the sign of the same
-// row applied to the unnormalised L - p as long as that sum is clear of its rounding error
-// (|d'.y m - g| <= 6 ulp of the sum of the terms' magnitudes).  When o'.y and d'.y share a
-// sign, t < 0, and when o'.y == 0, t == 0: `is_shadowed` (src/scene.rs:208-225) wants
-// t > 0 either way, so the square root and the divisions can be skipped.  Returns false only then.
-__device__ __forceinline__ bool plane_may_block(const RTK_RO DevObject& ob, const RTK_RO DevLight& L, V3 p) {
+// Can the reference's shadow ray from p towards light L meet a plane at a positive parameter?
+// `Plane::intersect` (src/scene/shapes/planes.rs:22-28) returns t = -o'.y / d'.y for the object-space
+// origin o' and direction d' = inverse * (L - p, L.w - 1)/m.  o'.y is formed here exactly as
+// intersect_object forms it.  d'.y m is row 1 of the inverse applied to (L - p, L.w - 1): in real
+// numbers G = row.(L, L.w - 1) - row.(p, 0), and both the reference's value and the difference g formed
+// here lie within a few ulp of the sum of the magnitudes of all those terms from G.  The light's part
+// and its magnitudes come per (plane, light) from scene upload (DevScene::plane_light), the point's
+// part once per (plane, point): two additions per light.  When g is clear of 1e-12 times the
+// magnitudes, d'.y has its sign; when o'.y and d'.y share a sign, t < 0, and when o'.y == 0, t == 0:
+// `is_shadowed` (src/scene.rs:208-225) wants t > 0 either way, so the square root and the divisions
+// can be skipped.  plane_may_block returns false only then.
+struct PlaneSide {
+  double oy;     // o'.y
+  double q;      // row.(p, 0)
+  double noise;  // 1e-12 x the magnitudes of q's terms
+};
+__device__ __forceinline__ PlaneSide plane_side(const RTK_RO DevObject& ob, V3 p) {
   const RTK_RO double* m = ob.inv;
-  const double oy = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
-  const double a = m[4] * (L.pos[0] - p.x), b = m[5] * (L.pos[1] - p.y), c = m[6] * (L.pos[2] - p.z), d = m[7] * (L.pos[3] - 1.0);
-  const double g = a + b + c + d;
-  const double noise = 1.0e-12 * (fabs(a) + fabs(b) + fabs(c) + fabs(d));
-  if (oy == 0.0) return false;
-  if (oy > 0.0 && g > noise) return false;
-  if (oy < 0.0 && g < -noise) return false;
+  const double a = m[4] * p.x, b = m[5] * p.y, c = m[6] * p.z;
+  PlaneSide s;
+  s.q = a + b + c;
+  s.oy = s.q + m[7];  // ((a + b) + c) + m[7], as in intersect_object
+  s.noise = 1.0e-12 * (fabs(a) + fabs(b) + fabs(c));
+  return s;
+}
+__device__ __forceinline__ bool plane_may_block(const PlaneSide& s, double2 plane_light) {
+  const double g = plane_light.x - s.q;
+  const double noise = plane_light.y + s.noise;
+  if (s.oy == 0.0) return false;
+  if (s.oy > 0.0 && g > noise) return false;
+  if (s.oy < 0.0 && g < -noise) return false;
   return true;
 }
 
@@ -172,13 +236,21 @@ __device__ __forceinline__ float filter_threshold(const DevScene& S, V3 pc, floa
 // ------------------------------------------------------------------------------------
 // Shading, all f64, following the reference line by line.
 
+// `x % 2.0 == 0.0` for an x that came out of floor() (or is a sum of such values): Rust's `%` is fmod,
+// and for an integer-valued x the remainder is zero exactly when x / 2 is an integer too (every double
+// from 2^53 on is even); fmod of an infinity is NaN, which equals nothing.
+__device__ __forceinline__ bool even_integer(double x) {
+  const double h = x * 0.5;
+  return fabs(x) < INFINITY && floor(h) == h;
+}
+
 // `Texture::sample_at` (src/scene/materials.rs:14-19) and the four patterns
-// (src/graphics/patterns.rs:57-65, 81-88, 105-116, 132-140).  Rust's `%` is fmod.
+// (src/graphics/patterns.rs:57-65, 81-88, 105-116, 132-140).
 __device__ __forceinline__ V3 sample_texture(const RTK_RO DevObject& ob, V3 p) {
   V3 a = ld3(ob.color_a), b = ld3(ob.color_b);
   switch (ob.texture_kind & 0xffu) {
     case 1u:  // checker
-      return (fmod(floor(p.x) + floor(p.y) + floor(p.z), 2.0) == 0.0) ? a : b;
+      return even_integer(floor(p.x) + floor(p.y) + floor(p.z)) ? a : b;
     case 2u: {  // gradient
       V3 distance = b - a;
       double fraction = p.x - floor(p.x);
@@ -186,10 +258,10 @@ __device__ __forceinline__ V3 sample_texture(const RTK_RO DevObject& ob, V3 p) {
     }
     case 3u: {  // ring
       double x2 = p.x * p.x, z2 = p.z * p.z;
-      return (fmod(floor(sqrt(x2 + z2)), 2.0) == 0.0) ? a : b;
+      return even_integer(floor(sqrt(x2 + z2))) ? a : b;
     }
     case 4u:  // striped
-      return (fmod(floor(p.x), 2.0) == 0.0) ? a : b;
+      return even_integer(floor(p.x)) ? a : b;
     default:
       return a;
   }
@@ -222,7 +294,7 @@ __device__ __forceinline__ HitGeom lighting_data(const RTK_RO DevObject& ob, V3 
     n = {m[0] * op.x + m[4] * op.y + m[8] * op.z, m[1] * op.x + m[5] * op.y + m[9] * op.z,
          m[2] * op.x + m[6] * op.y + m[10] * op.z};
     double mag = sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
-    n = {n.x / mag, n.y / mag, n.z / mag};
+    n = divide_by_length(n, mag);
   }
   // offsets, texture point and reflection use the normal BEFORE the inside flip
   h.over = world + n * 0.0001;
@@ -246,7 +318,7 @@ __device__ __forceinline__ V3 phong_lighting(const RTK_RO DevLight& L, const RTK
   V3 lv = ld3(L.pos) - over;
   double lw = L.pos[3] - 1.0;
   double mag = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
-  V3 ld = {lv.x / mag, lv.y / mag, lv.z / mag};
+  V3 ld = divide_by_length(lv, mag);
   V3 diffuse = {0, 0, 0}, specular = {0, 0, 0};
   double ldn = dot3(ld, normal);
   if (ldn >= 0.0) {
@@ -348,7 +420,7 @@ __device__ __forceinline__ V3 camera_ray_direction(const DevCamera& C, uint32_t 
   V3 pixel = xform(C.inv, V3{world_x, world_y, -1.0}, 1.0);
   V3 dv = pixel - ld3(C.origin);
   double mag = sqrt(dv.x * dv.x + dv.y * dv.y + dv.z * dv.z);
-  return {dv.x / mag, dv.y / mag, dv.z / mag};
+  return divide_by_length(dv, mag);
 }
 
 // Framebuffer store of one 32x8 tile (local tile k), transposed through LDS so that every

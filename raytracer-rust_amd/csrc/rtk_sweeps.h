@@ -250,16 +250,17 @@ __device__ __forceinline__ bool shadow_by_sweeps(const DevScene& S, bool active,
     uint32_t occl = 0;
     // planes: exact, per light (the shadow ray is rebuilt once per light)
     if (need) {
-      for (uint32_t r = 0; r < nb; ++r) {
-        const RTK_RO DevLight& L = S.lights[kb + r];
-        for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
-          const RTK_RO DevObject& ob = S.objects[S.plane_object[ip]];
-          if (!plane_may_block(ob, L, p)) continue;
+      for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
+        const RTK_RO DevObject& ob = S.objects[S.plane_object[ip]];
+        const PlaneSide side = plane_side(ob, p);
+        for (uint32_t r = 0; r < nb; ++r) {
+          const RTK_RO DevLight& L = S.lights[kb + r];
+          if (!plane_may_block(side, S.plane_light[ip * S.n_lights + kb + r])) continue;
           V3 lv = ld3(L.pos) - p;
           double lw = L.pos[3] - 1.0;
           double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
-          V3 d = {lv.x / m, lv.y / m, lv.z / m};
-          double dw = lw / m;
+          double dw;
+          V3 d = divide_by_length(lv, lw, m, dw);
           double t0, t1;
           int n = intersect_object(ob, p, d, dw, t0, t1);
           if (n >= 1 && t0 > 0.0 && t0 < m) occl |= 1u << r;
@@ -290,9 +291,10 @@ __device__ __forceinline__ bool shadow_by_sweeps(const DevScene& S, bool active,
         V3 lv = ld3(L.pos) - p;
         double lw = L.pos[3] - 1.0;
         double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
-        V3 d = {lv.x / m, lv.y / m, lv.z / m};
+        double dw;
+        V3 d = divide_by_length(lv, lw, m, dw);
         double t0, t1;
-        int n = intersect_sphere_record(S, rec, p, d, lw / m, t0, t1);
+        int n = intersect_sphere_record(S, rec, p, d, dw, t0, t1);
         ++n_exact;
         if (n == 2 && ((t0 > 0.0 && t0 < m) || (t1 > 0.0 && t1 < m))) occl |= 1u << r;
       }
@@ -349,13 +351,13 @@ __device__ __forceinline__ bool shadow_by_grids(const DevScene& S, bool active, 
     const V3 lv = ld3(L.pos) - p;
     const double lw = L.pos[3] - 1.0;
     const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
-    const V3 d = {lv.x / m, lv.y / m, lv.z / m};
-    const double dw = lw / m;
+    double dw;
+    const V3 d = divide_by_length(lv, lw, m, dw);
     if (need) {
       ++rays;
       for (uint32_t ip = 0; ip < S.n_planes; ++ip) {  // planes: exact
         const RTK_RO DevObject& ob = S.objects[S.plane_object[ip]];
-        if (!plane_may_block(ob, L, p)) continue;
+        if (!plane_may_block(plane_side(ob, p), S.plane_light[ip * S.n_lights + k])) continue;
         double t0, t1;
         const int n = intersect_object(ob, p, d, dw, t0, t1);
         if (n >= 1 && t0 > 0.0 && t0 < m) blocked = true;

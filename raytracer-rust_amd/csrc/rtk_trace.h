@@ -107,8 +107,8 @@ __device__ __forceinline__ bool shadow_brute(const DevScene& S, bool active, V3 
     const V3 lv = ld3(L.pos) - p;
     const double lw = L.pos[3] - 1.0;
     const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
-    const V3 d = {lv.x / m, lv.y / m, lv.z / m};
-    const double dw = lw / m;
+    double dw;
+    const V3 d = divide_by_length(lv, lw, m, dw);
     for (uint32_t obj = 0; obj < S.n_objects; ++obj) {
       double t0, t1;
       const int n = intersect_object(S.objects[obj], p, d, dw, t0, t1);

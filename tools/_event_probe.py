@@ -6,8 +6,8 @@ device = importlib.import_module("raytracer-rust_amd.device")
 device.LIB_PATH = os.path.abspath(os.environ["RTK_LIB"])
 dev = device.Device(0)
 lib = device.library()
-names = ["prim cluster opens", "prim level-2 spheres", "prim exact bodies", "shadow cluster opens", "shadow level-2 spheres",
-         "shadow candidate spheres", "shadow exact bodies (sphere x light)", "-"]
+names = ["shadow exact bodies", "bodies where every lane is behind", "bodies where no lane is blocked", "lanes behind AND blocked (must be 0)",
+         "lane tests", "lane tests behind", "lane tests blocked", "-"]
 for name, size in (("C4", (3840, 2160)), ("C3", (3840, 2160)), ("C2", (1920, 1080))):
     scene, camera = rtk.synthetic.config(name, *size)
     h = dev.upload(scene)

@@ -145,6 +145,51 @@ class FilterScene:
         return fma(h, h, e) >= thrp
 
 
+    # ---- spheres behind a shadow ray (BehindMargins and the hot loop of shadow_phase_uniform) -------
+    def tabulated_behind(self, p, light_xyz):
+        """The device drops ray i vs sphere i as 'behind': shadow ray from p [rays,3] towards ONE w = 0
+        light.  Margins per pixel (the device takes their maximum over a wavefront: never smaller)."""
+        p = np.asarray(p, np.float64)
+        Lv = np.asarray(light_xyz, np.float64)
+        inv = 1.0 / np.sqrt((Lv * Lv).sum())
+        gd = Lv * inv
+        rho_d = -inv
+        lf = np.array([gd[0], gd[1], gd[2], rho_d]).astype(F)
+        cfd = self.cf.astype(np.float64)
+        K = (cfd @ gd - self.r2.astype(np.float64) * rho_d).astype(F)
+        ball_r = round_up(np.sqrt(self.r2.astype(np.float64)) * (1.0 + 1e-7))   # sph_ball.w
+        pc = p - self.center
+        x, y, z = pc[:, 0].astype(F), pc[:, 1].astype(F), pc[:, 2].astype(F)
+        P = fma(z, lf[2], fma(y, lf[1], (x * lf[0]).astype(F)))
+        lrho = np.abs(lf[3]) * F(1.0001)
+        rho_max = float(lrho)
+        pn = np.sqrt((pc * pc).sum(axis=1))
+        B = float(self.r2_max) * rho_max
+        dh = float(EPS32) * (6.0 * pn + 2.0 * float(self.c_max) + 2.0 * B) * 1.01
+        hmax = pn + float(self.c_max) + B
+        e32 = float(EPS32)
+        reach = pn * (1.0 + e32) + float(self.c_max)
+        absolute = reach + np.abs(self.center).sum()
+        dp = pn * e32 * 1.0001
+        dd = dp + e32 * float(self.c_max) * 1.01
+
+        def above(v):
+            return np.nextafter(round_up(v), F(np.inf)).astype(F)
+        q1 = above(dp * 1.01 + 1.0e-12 * (absolute + reach))
+        q3 = above(dh * 1.01 + dd * (1.0 + rho_max * (2.0 * reach + dd)) * 1.01 +
+                   1.01 * e32 * (hmax + rho_max * (2.0 * reach * reach + float(self.r2_max))) +
+                   1.0e-12 * reach * (1.0 + 2.0 * rho_max * absolute))
+        # hot loop
+        ux, uy, uz = (x - self.cf[:, 0]).astype(F), (y - self.cf[:, 1]).astype(F), (z - self.cf[:, 2]).astype(F)
+        uu = fma(uz, uz, fma(uy, uy, (ux * ux).astype(F)))
+        dist = np.nextafter(np.sqrt(uu.astype(np.float64)).astype(F), F(np.inf))  # v_sqrt_f32 is good to 1 ulp: take the worst case
+        one_lo = F(1.0) - F(8.0) * EPS32
+        outside = fma(dist, one_lo, -ball_r) >= q1
+        rr = ((ball_r * ball_r).astype(F) * (F(1.0) - F(1.0e-6))).astype(F)
+        gap = (fma(uu, F(1.0) + F(8.0) * EPS32, -rr) * (F(1.0) + F(4.0) * EPS32)).astype(F)
+        h = (P - K).astype(F)
+        return outside & (fma(-lrho, gap, h) >= q3)
+
 # ---- wavefront-level tests (one sphere or cluster per lane against a bundle of 64 rays) -------
 
 def cluster_balls(cf, ball_r, bundle=64):

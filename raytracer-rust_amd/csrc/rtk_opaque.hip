@@ -1,6 +1,6 @@
 // rtk_opaque.hip -- the render path for scenes without reflective or transparent
 // materials (every throughput configuration).  One pixel per lane, one 8x8 patch per
-// wavefront, one 32x8 tile per workgroup.
+// wavefront, one 32x8 tile per workgroup (one patch per workgroup in the fused kernel).
 //
 //   render_uniform_kernel  every light has w = 0 (what scene files give): camera ray, the
 //                    shadow rays of its hit towards all lights (batches of 4), shading and
@@ -63,15 +63,19 @@ __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballo
 // divisions, fetching it back three 8-byte LDS reads).  One array of 256 doubles per component,
 // so a wavefront's lanes read consecutive addresses.  A lane only ever reads what it wrote itself:
 // no barrier is involved.
-struct Stash {
-  double dir[3][kBlock];     // unit camera-ray direction
-  double over[3][kBlock];    // over_position of the hit
-  double normal[3][kBlock];  // its (flipped) normal
+template <int N>  // threads of the workgroup
+struct StashOf {
+  double dir[3][N];     // unit camera-ray direction
+  double over[3][N];    // over_position of the hit
+  double normal[3][N];  // its (flipped) normal
 };
-__device__ __forceinline__ void put3(double (*a)[kBlock], V3 v) {
+using Stash = StashOf<kBlock>;
+template <int N>
+__device__ __forceinline__ void put3(double (*a)[N], V3 v) {
   a[0][threadIdx.x] = v.x, a[1][threadIdx.x] = v.y, a[2][threadIdx.x] = v.z;
 }
-__device__ __forceinline__ V3 get3(double (*a)[kBlock]) { return {a[0][threadIdx.x], a[1][threadIdx.x], a[2][threadIdx.x]}; }
+template <int N>
+__device__ __forceinline__ V3 get3(double (*a)[N]) { return {a[0][threadIdx.x], a[1][threadIdx.x], a[2][threadIdx.x]}; }
 
 // Where a thread's pixel sits: local tile k (global tile k*world + rank), slot (lx, ly).
 struct PixelRef {
@@ -80,9 +84,8 @@ struct PixelRef {
   bool in_range;   // the tile exists
   bool valid;      // ... and the pixel lies inside the frame
 };
-__device__ __forceinline__ PixelRef pixel_ref(const RenderTarget& T, const DevCamera& C, uint32_t k) {
+__device__ __forceinline__ PixelRef pixel_ref(const RenderTarget& T, const DevCamera& C, uint32_t k, uint32_t wave, uint32_t lane) {
   PixelRef p;
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t lx = (wave << 3) | (lane & 7u), ly = lane >> 3;
   p.in_range = k < T.n_local_tiles;
   const TileRef tr = tile_ref(T, k);
@@ -91,6 +94,9 @@ __device__ __forceinline__ PixelRef pixel_ref(const RenderTarget& T, const DevCa
   p.valid = p.in_range && p.x < C.width && p.y < C.height;
   p.local = k * 256u + ly * 32u + lx;
   return p;
+}
+__device__ __forceinline__ PixelRef pixel_ref(const RenderTarget& T, const DevCamera& C, uint32_t k) {
+  return pixel_ref(T, C, k, threadIdx.x >> 6, threadIdx.x & 63u);
 }
 
 // ------------------------------------------------------------------------------------
@@ -127,10 +133,11 @@ __device__ __forceinline__ bool cone_reaches(const Cone& c, float4 ball) {
 // ------------------------------------------------------------------------------------
 // Camera-ray phase of one pixel per lane; each wavefront owns one 8x8 patch.  Planes exact,
 // spheres through the three levels (clusters, members, per-ray filter) and f64 on what is left.
+template <typename StashT = Stash>
 __device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera& C, const float4* __restrict__ prim,
                                               const float4* __restrict__ prim_ball,
                                               const float4* __restrict__ prim_cluster, const PixelRef& px, Closest& best,
-                                              unsigned& n_exact, Stash* stash = nullptr) {
+                                              unsigned& n_exact, StashT* stash = nullptr) {
   const V3 origin = ld3(C.origin);
   const uint32_t lane = threadIdx.x & 63u;
   closest_init(best);
@@ -723,7 +730,8 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, 
 
 // `apply_lighting` for the fused kernel: the hit geometry comes back from the stash
 // (LightingData::calculate ran once, in the shadow set-up) instead of being derived again.
-__device__ __forceinline__ V3 shade_hit_stashed(const DevScene& S, uint32_t obj, bool in_shadow, Stash* stash) {
+template <typename StashT>
+__device__ __forceinline__ V3 shade_hit_stashed(const DevScene& S, uint32_t obj, bool in_shadow, StashT* stash) {
   const RTK_RO DevObject& ob = S.objects[obj];
   const V3 over = get3(stash->over), normal = get3(stash->normal), eye = -get3(stash->dir);
   const V3 objp = xform(ob.inv, over, 1.0);  // as LightingData computes it (src/scene/lighting.rs:52)
@@ -735,19 +743,47 @@ __device__ __forceinline__ V3 shade_hit_stashed(const DevScene& S, uint32_t obj,
 }
 
 // All three steps in one kernel (every light has w = 0 or 1): no hit records cross HBM.
-// Five wavefronts per SIMD: with the object records in scalar registers the kernel needs 89 VGPRs
-// and no scratch (built without machine LICM, see the Makefile); C4 0.78 ms against 0.86 at four
-// wavefronts, a 4096^2 C5 1.31 against 1.48.  Six wavefronts spill 88 bytes per lane for no gain.
+// Five wavefronts per SIMD: with the object records in scalar registers the kernel needs 96 VGPRs
+// (built without machine LICM, see the Makefile).
+// ONE wavefront per workgroup (an 8x8 patch, a quarter of a tile).  The four wavefronts of a tile differ
+// in what their patches cost; as one workgroup the fast ones waited for the slow one -- at the barrier
+// of a store transposed through LDS, and then for the workgroup's registers and LDS to be released
+// together (a sixth of a wavefront's lifetime on C4; a 4096^2 C5 frame 1.07 -> 0.89 ms without).  Here
+// a wavefront stores its own 64 pixels (rows of 8: 32 bytes of RGBA8, 96 of FP32) and leaves.
+// Workgroups go round the eight XCDs, each with an L2 of its own, so the quarters of a tile are given
+// to consecutive workgroups OF ONE XCD: its L2 sees the whole 128- and 384-byte tile rows before it
+// writes them back.
+constexpr uint32_t kXcds = 8;
+__device__ __forceinline__ void store_patch(const DevCamera& C, const RenderTarget& T, uint32_t k, uint32_t quarter, V3 color) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t lx = (quarter << 3) | (lane & 7u), ly = lane >> 3;
+  const TileRef tr = tile_ref(T, k);
+  const uint32_t x = tr.tx * 32u + lx, y = tr.ty * 8u + ly;
+  size_t at;  // pixel index in the output
+  if (T.layout == 1u) {
+    at = (size_t)k * 256u + ly * 32u + lx;
+  } else {
+    if (x >= C.width || y >= C.height) return;
+    at = (size_t)x + (size_t)((T.layout == 2u ? tr.lrow : tr.ty) * 8u + ly) * C.width;
+  }
+  if (T.rgba8) reinterpret_cast<uint32_t*>(T.rgba8)[at] = cast_u8(color.x) | (cast_u8(color.y) << 8) | (cast_u8(color.z) << 16) | 0xff000000u;
+  if (T.rgb) {
+    float* out = T.rgb + at * 3u;
+    out[0] = (float)color.x, out[1] = (float)color.y, out[2] = (float)color.z;
+  }
+}
 template <int KW, bool TABULATED>
-__global__ void __launch_bounds__(kBlock, 5) render_uniform_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
-                                                                  const float4* __restrict__ prim_ball,
-                                                                  const float4* __restrict__ prim_cluster, RenderTarget T,
-                                                                  DevCounters* counters) {
-  __shared__ float s_rgb[768];
-  __shared__ uint32_t s_px[256];
-  __shared__ Stash stash;
-  const uint32_t k = T.n_local_tiles - 1u - blockIdx.x;
-  const PixelRef px = pixel_ref(T, C, k);
+__global__ void __launch_bounds__(64, 5) render_uniform_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
+                                                            const float4* __restrict__ prim_ball,
+                                                            const float4* __restrict__ prim_cluster, RenderTarget T,
+                                                            DevCounters* counters) {
+  __shared__ StashOf<64> stash;
+  // workgroup b runs on XCD b % 8; its XCD's workgroups 4t .. 4t + 3 are the quarters of one tile
+  const uint32_t xcd = blockIdx.x % kXcds, slot = blockIdx.x / kXcds;
+  const uint32_t quarter = slot & 3u, tile = (slot >> 2) * kXcds + xcd;
+  if (tile >= T.n_local_tiles) return;
+  const uint32_t k = T.n_local_tiles - 1u - tile;
+  const PixelRef px = pixel_ref(T, C, k, quarter, threadIdx.x);
   Closest best;
   unsigned n_exact = 0;
   primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, n_exact, &stash);
@@ -765,14 +801,15 @@ __global__ void __launch_bounds__(kBlock, 5) render_uniform_kernel(DevScene S, D
                                    : shadow_phase_bundled<KW>(S, hit, p, rays, n_exact);
   V3 color = {0, 0, 0};
   if (px.valid) color = hit ? shade_hit_stashed(S, launder(obj), in_shadow, &stash) : ld3(S.ambient);
-  store_tile(C, T, k, color, s_rgb, s_px);
+  store_patch(C, T, k, quarter, color);
   const unsigned n_primary = wave_sum(px.valid ? 1u : 0u);
   rays = wave_sum(rays);
   n_exact = wave_sum(n_exact);
-  if ((threadIdx.x & 63u) == 0) {
-    atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)n_primary);
-    atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)rays);
-    atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
+  if (threadIdx.x == 0) {
+    DevCounters* mine = counters + (tile % kCounterShards);
+    atomicAdd(&mine->rays_primary, (unsigned long long)n_primary);
+    atomicAdd(&mine->rays_shadow, (unsigned long long)rays);
+    atomicAdd(&mine->exact_tests, (unsigned long long)n_exact);
   }
 }
 
@@ -848,10 +885,11 @@ hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCame
     // everything in one kernel; lights are swept in batches of 4 (the cluster levels cost next
     // to nothing per batch, and 128 VGPRs hold the 4-light filter state without spills).  Lights
     // built from points (w == 1) add cones with their apex at the light.
+    const dim3 patches((T.n_local_tiles + kXcds - 1u) / kXcds * kXcds * 4u), wavefront(64);
     if (S.lights_uniform)
-      hipLaunchKernelGGL((render_uniform_kernel<4, true>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, counters);
+      hipLaunchKernelGGL((render_uniform_kernel<4, true>), patches, wavefront, 0, st, S, C, prim, prim_ball, prim_cluster, T, counters);
     else
-      hipLaunchKernelGGL((render_uniform_kernel<4, false>), tiles, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, counters);
+      hipLaunchKernelGGL((render_uniform_kernel<4, false>), patches, wavefront, 0, st, S, C, prim, prim_ball, prim_cluster, T, counters);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return after_rays ? hipEventRecord(after_rays, st) : hipSuccess;
   }

@@ -295,7 +295,7 @@ def main():
                 if avg_kernel_ms > 0 else None,  # sanity counter: 12 B FP32 RGB + 4 B RGBA8 per pixel, written once
                 "note": "achieved = f64 flops the kernel executes per launch (PMC instruction mix x 64 lanes x share of lanes "
                         "active; fma = 2) / HIP-event time of that kernel in this run; peak = vector f64 peak (256 CUs x 2.4 GHz x "
-                        "128 flop/clk/CU). The kernel is bound by instruction issue (VALU busy ~3/4 of cycles, a third of them moves, selects and "
+                        "128 flop/clk/CU). The kernel is bound by instruction issue (VALU busy ~2/3 of cycles by the instruction mix, a third of the instructions moves, selects and "
                         "compares) and dependent-load latency at 5 waves per SIMD, not by f64 arithmetic",
             },
             "reference_sweep_equivalent": {

@@ -82,13 +82,14 @@ __device__ __forceinline__ void store_pixel(const DevCamera& C, const RenderTarg
 // of it, which is worth more there than keeping every lane busy (bundled scene at 1080p: 0.52 ms
 // against 0.74 ms with persistent lanes).  One lane per pixel of a 32x8 tile, as in the opaque path.
 template <bool TRACK>
-__global__ void __launch_bounds__(kBlock, 4) render_small_kernel(DevScene S, DevCamera C, RenderTarget T, DevCounters* counters) {
-  __shared__ float s_rgb[768];  // store transpose only
-  __shared__ uint32_t s_px[256];
+__global__ void __launch_bounds__(64, 4) render_small_kernel(DevScene S, DevCamera C, RenderTarget T, DevCounters* counters) {
+  // one wavefront per workgroup (patch_of_group): ray trees differ from patch to patch
+  const PatchOfGroup pg = patch_of_group();
+  if (pg.tile >= T.n_local_tiles) return;
   // expensive tiles (ground, bottom of the frame) first, cheap sky tiles last
-  const uint32_t k = T.n_local_tiles - 1u - blockIdx.x;
+  const uint32_t k = T.n_local_tiles - 1u - pg.tile;
   const TileRef tr = tile_ref(T, k);
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t wave = pg.quarter, lane = threadIdx.x & 63u;
   const uint32_t lx = (wave << 3) | (lane & 7u), ly = lane >> 3;
   const uint32_t x = tr.tx * 32u + lx, y = tr.ty * 8u + ly;
   const bool valid = x < C.width && y < C.height;
@@ -96,14 +97,15 @@ __global__ void __launch_bounds__(kBlock, 4) render_small_kernel(DevScene S, Dev
   const V3 dir = camera_ray_direction(C, x, y);  // cameras.rs:52-69
   unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
   V3 color = trace_ray<true, false, 1, false, true, TRACK>(S, nullptr, nullptr, valid, origin, dir, c_primary, c_shadow, c_secondary, c_exact);
-  store_tile(C, T, k, color, s_rgb, s_px);
+  store_patch(C, T, k, pg.quarter, color);
   c_primary = wave_sum(c_primary);
   c_shadow = wave_sum(c_shadow);
   c_secondary = wave_sum(c_secondary);
   if (lane == 0) {
-    atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)c_primary);
-    atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)c_shadow);
-    atomicAdd(&counter_shard(counters)->rays_secondary, (unsigned long long)c_secondary);
+    DevCounters* mine = counters + (pg.tile % kCounterShards);
+    atomicAdd(&mine->rays_primary, (unsigned long long)c_primary);
+    atomicAdd(&mine->rays_shadow, (unsigned long long)c_shadow);
+    atomicAdd(&mine->rays_secondary, (unsigned long long)c_secondary);
   }
 }
 
@@ -434,9 +436,9 @@ hipError_t launch_render(hipStream_t st, const DevScene& S, const DevCamera& C, 
   const bool track = S.track_n1 != 0;
   if (S.n_objects <= kBruteObjects) {
     if (track)
-      hipLaunchKernelGGL((render_small_kernel<true>), dim3(T.n_local_tiles), dim3(kBlock), 0, st, S, C, T, counters);
+      hipLaunchKernelGGL((render_small_kernel<true>), dim3(patch_groups(T.n_local_tiles)), dim3(64), 0, st, S, C, T, counters);
     else
-      hipLaunchKernelGGL((render_small_kernel<false>), dim3(T.n_local_tiles), dim3(kBlock), 0, st, S, C, T, counters);
+      hipLaunchKernelGGL((render_small_kernel<false>), dim3(patch_groups(T.n_local_tiles)), dim3(64), 0, st, S, C, T, counters);
     return hipGetLastError();
   }
   // Level by level where the scene has secondary rays to queue; the depth-first kernel below then

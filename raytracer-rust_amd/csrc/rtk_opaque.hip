@@ -753,36 +753,16 @@ __device__ __forceinline__ V3 shade_hit_stashed(const DevScene& S, uint32_t obj,
 // Workgroups go round the eight XCDs, each with an L2 of its own, so the quarters of a tile are given
 // to consecutive workgroups OF ONE XCD: its L2 sees the whole 128- and 384-byte tile rows before it
 // writes them back.
-constexpr uint32_t kXcds = 8;
-__device__ __forceinline__ void store_patch(const DevCamera& C, const RenderTarget& T, uint32_t k, uint32_t quarter, V3 color) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t lx = (quarter << 3) | (lane & 7u), ly = lane >> 3;
-  const TileRef tr = tile_ref(T, k);
-  const uint32_t x = tr.tx * 32u + lx, y = tr.ty * 8u + ly;
-  size_t at;  // pixel index in the output
-  if (T.layout == 1u) {
-    at = (size_t)k * 256u + ly * 32u + lx;
-  } else {
-    if (x >= C.width || y >= C.height) return;
-    at = (size_t)x + (size_t)((T.layout == 2u ? tr.lrow : tr.ty) * 8u + ly) * C.width;
-  }
-  if (T.rgba8) reinterpret_cast<uint32_t*>(T.rgba8)[at] = cast_u8(color.x) | (cast_u8(color.y) << 8) | (cast_u8(color.z) << 16) | 0xff000000u;
-  if (T.rgb) {
-    float* out = T.rgb + at * 3u;
-    out[0] = (float)color.x, out[1] = (float)color.y, out[2] = (float)color.z;
-  }
-}
 template <int KW, bool TABULATED>
 __global__ void __launch_bounds__(64, 5) render_uniform_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                             const float4* __restrict__ prim_ball,
                                                             const float4* __restrict__ prim_cluster, RenderTarget T,
                                                             DevCounters* counters) {
   __shared__ StashOf<64> stash;
-  // workgroup b runs on XCD b % 8; its XCD's workgroups 4t .. 4t + 3 are the quarters of one tile
-  const uint32_t xcd = blockIdx.x % kXcds, slot = blockIdx.x / kXcds;
-  const uint32_t quarter = slot & 3u, tile = (slot >> 2) * kXcds + xcd;
+  const PatchOfGroup pg = patch_of_group();
+  const uint32_t quarter = pg.quarter, tile = pg.tile;
   if (tile >= T.n_local_tiles) return;
-  const uint32_t k = T.n_local_tiles - 1u - tile;
+  const uint32_t k = T.n_local_tiles - 1u - tile;  // expensive tiles (bottom of the frame) first
   const PixelRef px = pixel_ref(T, C, k, quarter, threadIdx.x);
   Closest best;
   unsigned n_exact = 0;
@@ -885,7 +865,7 @@ hipError_t launch_render_opaque(hipStream_t st, const DevScene& S, const DevCame
     // everything in one kernel; lights are swept in batches of 4 (the cluster levels cost next
     // to nothing per batch, and 128 VGPRs hold the 4-light filter state without spills).  Lights
     // built from points (w == 1) add cones with their apex at the light.
-    const dim3 patches((T.n_local_tiles + kXcds - 1u) / kXcds * kXcds * 4u), wavefront(64);
+    const dim3 patches(patch_groups(T.n_local_tiles)), wavefront(64);
     if (S.lights_uniform)
       hipLaunchKernelGGL((render_uniform_kernel<4, true>), patches, wavefront, 0, st, S, C, prim, prim_ball, prim_cluster, T, counters);
     else

@@ -469,5 +469,44 @@ __device__ __forceinline__ void store_tile(const DevCamera& C, const RenderTarge
   }
 }
 
+// Workgroups of ONE wavefront that own an 8x8 patch, a quarter of a 32x8 tile (kernels whose
+// wavefronts cost very different amounts: as one workgroup per tile the fast wavefronts of a tile would
+// wait for the slow one, at the store's barrier and for the release of the workgroup's resources).
+// Workgroups go round the eight XCDs, each with an L2 of its own; the quarters of a tile are given to
+// consecutive workgroups OF ONE XCD, so that its L2 sees the whole 128- and 384-byte tile rows before
+// it writes them back.  Launch patch_groups(n_tiles) workgroups of 64 threads; those whose tile is
+// >= n_tiles have nothing to do.
+constexpr uint32_t kXcds = 8;
+struct PatchOfGroup {
+  uint32_t tile, quarter;
+};
+__device__ __forceinline__ PatchOfGroup patch_of_group() {
+  // workgroup b runs on XCD b % 8; its XCD's workgroups 4t .. 4t + 3 are the quarters of one tile
+  const uint32_t xcd = blockIdx.x % kXcds, slot = blockIdx.x / kXcds;
+  return {(slot >> 2) * kXcds + xcd, slot & 3u};
+}
+inline uint32_t patch_groups(uint32_t n_tiles) { return (n_tiles + kXcds - 1u) / kXcds * kXcds * 4u; }
+
+// The wavefront's own 64 pixels of local tile k, straight from the lanes (rows of 8: 32 bytes of RGBA8,
+// 96 of FP32); layouts as in store_tile.
+__device__ __forceinline__ void store_patch(const DevCamera& C, const RenderTarget& T, uint32_t k, uint32_t quarter, V3 color) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t lx = (quarter << 3) | (lane & 7u), ly = lane >> 3;
+  const TileRef tr = tile_ref(T, k);
+  const uint32_t x = tr.tx * 32u + lx, y = tr.ty * 8u + ly;
+  size_t at;  // pixel index in the output
+  if (T.layout == 1u) {
+    at = (size_t)k * 256u + ly * 32u + lx;
+  } else {
+    if (x >= C.width || y >= C.height) return;
+    at = (size_t)x + (size_t)((T.layout == 2u ? tr.lrow : tr.ty) * 8u + ly) * C.width;
+  }
+  if (T.rgba8) reinterpret_cast<uint32_t*>(T.rgba8)[at] = cast_u8(color.x) | (cast_u8(color.y) << 8) | (cast_u8(color.z) << 16) | 0xff000000u;
+  if (T.rgb) {
+    float* out = T.rgb + at * 3u;
+    out[0] = (float)color.x, out[1] = (float)color.y, out[2] = (float)color.z;
+  }
+}
+
 }  // namespace rtk
 #endif

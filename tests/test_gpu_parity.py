@@ -355,6 +355,53 @@ def test_lights_near_the_origin_and_inside_the_field(rtk, dev, oracle):
     check_against_oracle(dev, oracle, scene, _field_camera(rtk, E, 160, 90), "near lights")
 
 
+@pytest.mark.parametrize("case", ["close lights", "far field", "tiny spheres", "mirrored and squashed", "inside"])
+def test_spheres_behind_their_shadow_rays(rtk, dev, oracle, case):
+    """The fused kernel leaves out the exact test of a sphere an FP32 test proves to lie behind the
+    shadow ray (mostly the sphere the pixel sits on).  Scenes at the edges of that proof: w = 0 lights a
+    radius away from spheres and inside one; a field 20,000 units from the origin (FP32 cannot tell a
+    point from its surface there); spheres a thousandth of the field in radius; spheres with a negative
+    uniform scale (one radius all the same) among squashed and rotated ones (never admitted); the
+    camera inside a large sphere (shading points stand INSIDE the surface)."""
+    M = rtk.Matrix4x4
+    rng = np.random.default_rng({"close lights": 1, "far field": 2, "tiny spheres": 3, "mirrored and squashed": 4, "inside": 5}[case])
+    E = 15.0
+    off = np.array([2.0e4, -1.0e4, 3.0e4]) if case == "far field" else np.zeros(3)
+    lights = [rtk.vec3(-0.8 * E, 1.5 * E, -0.5 * E), rtk.vec3(0.9 * E, 1.1 * E, 0.3 * E), rtk.vec3(0.1 * E, 2.0 * E, 2.5 * E)]
+    if case == "close lights":
+        lights = [rtk.vec3(0.0, 2.1, 0.9 * E), rtk.vec3(3.0, 1.0, 0.5 * E), rtk.vec3(-4.0, 0.6, 1.2 * E), rtk.vec3(0.5, 0.5, 0.6 * E)]
+    if case == "far field":
+        lights = [rtk.vec3(*(off + np.array([-0.8 * E, 1.5 * E, -0.5 * E]))), rtk.vec3(*(off + np.array([0.9 * E, 1.1 * E, 0.3 * E])))]
+    scene = rtk.Scene()
+    for pos in lights:
+        scene.add_light(rtk.PointLight(pos, rtk.rgb(*(1.0 / len(lights),) * 3)))
+    mat = rtk.Material.default()
+    scene.add_object(rtk.Plane().with_material(mat.with_pattern(rtk.Texture.checker(rtk.WHITE, rtk.BLACK)).with_specular(0.0))
+                     .with_transform(M.translate(*off)))
+    r_lo, r_hi = (0.01, 0.03) if case == "tiny spheres" else (0.2, 2.5)
+    for i in range(500):
+        r = float(np.exp(rng.uniform(np.log(r_lo), np.log(r_hi))))
+        c = off + np.array([rng.uniform(-E, E), rng.uniform(0.0, 0.4 * E), rng.uniform(0.0, 2 * E)])
+        t = M.translate(*c)
+        kind = i % 4 if case == "mirrored and squashed" else 0
+        if kind == 1:
+            t = t * M.scale(-r, -r, -r)
+        elif kind == 2:
+            t = t * M.scale(r, 0.5 * r, r)
+        elif kind == 3:
+            t = t * M.rotate_y(rng.uniform(0, 6.28)) * M.scale(r, r, r)
+        else:
+            t = t * M.scale(r, r, r)
+        scene.add_object(rtk.Sphere().with_material(mat.with_color(rtk.rgb(*rng.uniform(0.2, 1.0, size=3)))).with_transform(t))
+    if case == "close lights":  # a light inside this one
+        scene.add_object(rtk.Sphere().with_material(mat).with_transform(M.translate(0.5, 0.5, 0.6 * E) * M.scale(1.5, 1.5, 1.5)))
+    eye, to = off + np.array([0, 0.5 * E, -0.6 * E]), off + np.array([0, 0, 0.9 * E])
+    if case == "inside":
+        scene.add_object(rtk.Sphere().with_material(mat.with_color(rtk.rgb(0.8, 0.7, 0.6))).with_transform(M.translate(0, 0, 0) * M.scale(60, 60, 60)))
+    camera = _field_camera(rtk, E, 160, 90, eye=rtk.point(*eye), to=rtk.point(*to))
+    check_against_oracle(dev, oracle, scene, camera, f"behind test: {case}")
+
+
 def test_clustered_field_w1_and_mixed_lights(rtk, dev, oracle):
     """Lights built from points (w = 1) and a mix of w = 0 / w = 1 take the two-kernel path."""
     rng = np.random.default_rng(5)

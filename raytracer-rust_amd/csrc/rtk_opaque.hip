@@ -287,11 +287,6 @@ __device__ __forceinline__ void park(PixelFilter<KW>& f) {
   for (int k = 0; k < KW; ++k) f.P[k] = 0.0f;
   f.thrp = 3.0e38f;
 }
-__device__ __forceinline__ float float_above(double v) {
-  float r = (float)v;
-  if ((double)r < v) r = nextafterf(r, INFINITY);
-  return nextafterf(r, INFINITY);
-}
 template <int KW>
 __device__ __forceinline__ void arm(PixelFilter<KW>& f, const DevScene& S, V3 p, uint32_t kb, uint32_t nb, BehindMargins& bm) {
   const V3 pc = {p.x - S.center[0], p.y - S.center[1], p.z - S.center[2]};
@@ -307,29 +302,34 @@ __device__ __forceinline__ void arm(PixelFilter<KW>& f, const DevScene& S, V3 p,
   //  - h = P - K, a difference of rounded numbers: |dh| <= eps (6|p| + 2 c_max + 2B)
   //  - the expanded |u|^2: roundings of p.c, CC and the two fused multiply-adds,
   //    <= eps (5|p|^2 + 6 c_max^2 + 2 R_max^2)
-  const double pn2 = dot3(pc, pc), pn = sqrt(pn2);
-  const double B = (double)S.r2_max * (double)rho_max;
-  const double dh = (double)kEps32 * (6.0 * pn + 2.0 * (double)S.c_max + 2.0 * B) * 1.01;
-  const double hmax = pn + (double)S.c_max + B;
-  const double cm2 = (double)S.c_max * (double)S.c_max;
-  const double extra = 2.0 * hmax * dh + dh * dh + 6.0 * (double)kEps32 * (pn2 + cm2 + (double)S.r2_max) * 1.01;
-  const double thr = (double)filter_threshold(S, pc, rho_max) - extra * 1.001;
+  // The bounds are sums and products of non-negative terms: they are evaluated in FP32 (two dozen
+  // operations, a few 1e-6 of relative error at most) and inflated by 1e-4, which keeps them above the
+  // f64 expressions they stand for (tests/filter_model.py evaluates those); only |f|^2 in the threshold
+  // itself needs all its digits.
+  const float e32 = kEps32, up = 1.0f + 1.0e-4f;
+  const float pn2 = __builtin_fmaf(f.z, f.z, __builtin_fmaf(f.y, f.y, f.x * f.x));  // |pc|^2 within a few eps
+  const float pn = __builtin_amdgcn_sqrtf(pn2);
+  const float B = S.r2_max * rho_max;
+  const float dh = e32 * (6.0f * pn + 2.0f * S.c_max + 2.0f * B) * 1.01f;
+  const float hmax = pn + S.c_max + B;
+  const float extra = 2.0f * hmax * dh + dh * dh + 6.0f * e32 * (pn2 + S.c_max * S.c_max + S.r2_max) * 1.01f;
+  const float dp = pn * e32 * 1.0001f;  // rounding of the recentred point (as in filter_threshold)
+  const float r2s = 2.0f * S.r_max * dp + dp * dp;
+  const float slack = r2s * (1.0f + 2.0f * hmax * rho_max) + 64.0f * e32 * (B * B + S.r2_max);
+  const float thr = -((slack + extra) * 1.001f * up + 1.0e-30f);
   const double pp = (double)f.x * f.x + (double)f.y * f.y + (double)f.z * f.z;
-  const double t = (double)kKappa * pp + thr;
+  const double t = (double)kKappa * pp + (double)thr;
   float tf = (float)t;
   if ((double)tf > t) tf = nextafterf(tf, -INFINITY);
   f.thrp = nextafterf(tf, -INFINITY);
   // margins of the behind test
-  const double e32 = (double)kEps32;
-  const double reach = pn * (1.0 + e32) + (double)S.c_max;  // >= |u32| for every sphere
-  const double absolute = reach + fabs(S.center[0]) + fabs(S.center[1]) + fabs(S.center[2]);  // >= |p| + |centre| in world coordinates
-  const double dp = pn * e32 * 1.0001;                   // rounding of the recentred point (as in filter_threshold)
-  const double dd = dp + e32 * (double)S.c_max * 1.01;   // ... and of a recentred centre
-  const double rho = (double)rho_max;
-  bm.q1 = float_above(dp * 1.01 + 1.0e-12 * (absolute + reach));
-  bm.q3 = float_above(dh * 1.01 + dd * (1.0 + rho * (2.0 * reach + dd)) * 1.01 +
-                      1.01 * e32 * (hmax + rho * (2.0 * reach * reach + (double)S.r2_max)) +
-                      1.0e-12 * reach * (1.0 + 2.0 * rho * absolute));
+  const float reach = pn * (1.0f + e32) + S.c_max;  // >= |u32| for every sphere
+  const float absolute = reach + (float)fabs(S.center[0]) + (float)fabs(S.center[1]) + (float)fabs(S.center[2]);  // >= |p| + |centre| in world coordinates
+  const float dd = dp + e32 * S.c_max * 1.01f;      // rounding of the recentred point and of a recentred centre
+  bm.q1 = (dp * 1.01f + 1.0e-12f * (absolute + reach)) * up + 1.0e-30f;
+  bm.q3 = (dh * 1.01f + dd * (1.0f + rho_max * (2.0f * reach + dd)) * 1.01f +
+           1.01f * e32 * (hmax + rho_max * (2.0f * reach * reach + S.r2_max)) +
+           1.0e-12f * reach * (1.0f + 2.0f * rho_max * absolute)) * up + 1.0e-30f;
 }
 constexpr float kTwoKappa = 2.0f * kKappa;
 

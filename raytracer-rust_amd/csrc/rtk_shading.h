@@ -310,6 +310,37 @@ __device__ __forceinline__ HitGeom lighting_data(const RTK_RO DevObject& ob, V3 
   return h;
 }
 
+// `reflect_dot_eye.powf(material.shininess)` (src/scene/lighting.rs:143-147).  The reference's powf is the C
+// library's pow: the correctly rounded power in all but a few cases per ten thousand.  The device library's
+// pow is 260 instructions (a logarithm and an exponential in extended precision) and only good to an ulp.
+// For an integer-valued exponent n in 1 .. 4095 -- every scene file's shininess -- the power is formed by
+// squaring and multiplying, left to right over the bits of n, on an unevaluated sum h + l: every product is
+// split exactly into its rounded value and its rounding error with one fused multiply-add, and the error
+// terms ride along (the l^2 terms left out are below 2^-80 of the result).  The rounded sum h + l is the
+// correctly rounded power (tests/test_powi_model.py restates the sequence against exact arithmetic), seven
+// rounds of 7 f64 operations for n = 200.  A skipped multiplication is a multiplication by 1.0, which
+// changes neither h nor l.  Below 2^-900 the error terms go subnormal and the last bits may differ from
+// the library's; such a factor reaches no pixel (it is below FP32's range, and zero after the 8-bit cast).
+// Other exponents (fractions, zero, negatives, 4096 and more) go to the library's pow.
+__device__ __forceinline__ double highlight_power(double x, double shininess) {
+  const double nf = floor(shininess);
+  if (!(nf == shininess && shininess >= 1.0 && shininess < 4096.0 && x >= 0.0 && x < 2.0)) return pow(x, shininess);
+  const uint32_t n = (uint32_t)nf;
+  double h = x, l = 0.0;
+  for (int b = 30 - (int)__builtin_clz(n); b >= 0; --b) {
+    double p = h * h;
+    double e = __builtin_fma(h, h, -p);
+    e = __builtin_fma(h + h, l, e);
+    h = p, l = e;
+    const double m = ((n >> b) & 1u) ? x : 1.0;
+    p = h * m;
+    e = __builtin_fma(h, m, -p);
+    e = __builtin_fma(l, m, e);
+    h = p, l = e;
+  }
+  return h + l;
+}
+
 // `phong_lighting` (src/scene/lighting.rs:120-154) for one light; `tex` is the sampled
 // texture colour.  The light vector is normalised over four components: its w is
 // L.w - 1 (the shading point has w = 1).
@@ -341,7 +372,7 @@ __device__ __forceinline__ V3 phong_lighting(const RTK_RO DevLight& L, const RTK
       const float lg_room = __log2f((float)base_min / (float)gain) - 55.0f;  // NaN or -inf when there is no room
       const bool negligible = sh > 0.0f && sh < 1.0e6f && rde <= 1.0 && base_min > 0.0 && lg_factor < lg_room;
       if (!negligible) {
-        double factor = pow(rde, ob.shininess);
+        double factor = highlight_power(rde, ob.shininess);
         specular = (intensity * ob.specular) * factor;
       }
     }

@@ -108,7 +108,11 @@ struct Cone {
 };
 __device__ __forceinline__ Cone make_cone(float dx, float dy, float dz) {
   Cone c;
-  float sx = wave_sum_f(dx), sy = wave_sum_f(dy), sz = wave_sum_f(dz);
+  // axis: between the directions of the two pixels either side of the patch's centre (lanes 27 and 36 of
+  // the 8x8 patch).  Any axis is sound -- the half-angle below is the largest angle any lane's ray makes
+  // with it -- and this one is within a hundredth of a pixel of the mean direction.
+  const float sx = lane_value(dx, 27u) + lane_value(dx, 36u), sy = lane_value(dy, 27u) + lane_value(dy, 36u),
+              sz = lane_value(dz, 27u) + lane_value(dz, 36u);
   const float inv = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz);
   c.ax = wave_uniform(sx * inv), c.ay = wave_uniform(sy * inv), c.az = wave_uniform(sz * inv);
   const float along = dx * c.ax + dy * c.ay + dz * c.az;
@@ -200,7 +204,7 @@ __global__ void __launch_bounds__(kBlock, 4) primary_kernel(DevScene S, DevCamer
   primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, n_exact);
   B.hit_obj[px.local] = px.valid ? best.obj : 0xffffffffu;
   B.hit_t[px.local] = best.t;
-  const unsigned n_primary = wave_sum(px.valid ? 1u : 0u);
+  const unsigned n_primary = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(px.valid));
   n_exact = wave_sum(n_exact);
   if ((threadIdx.x & 63u) == 0) {
     atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)n_primary);
@@ -287,8 +291,9 @@ __device__ __forceinline__ void park(PixelFilter<KW>& f) {
   for (int k = 0; k < KW; ++k) f.P[k] = 0.0f;
   f.thrp = 3.0e38f;
 }
+// Returns |pc| (FP32), the one per-pixel quantity the margins of the behind test depend on.
 template <int KW>
-__device__ __forceinline__ void arm(PixelFilter<KW>& f, const DevScene& S, V3 p, uint32_t kb, uint32_t nb, BehindMargins& bm) {
+__device__ __forceinline__ float arm(PixelFilter<KW>& f, const DevScene& S, V3 p, uint32_t kb, uint32_t nb) {
   const V3 pc = {p.x - S.center[0], p.y - S.center[1], p.z - S.center[2]};
   f.x = (float)pc.x, f.y = (float)pc.y, f.z = (float)pc.z;
   float rho_max = 0.0f;
@@ -322,14 +327,27 @@ __device__ __forceinline__ void arm(PixelFilter<KW>& f, const DevScene& S, V3 p,
   float tf = (float)t;
   if ((double)tf > t) tf = nextafterf(tf, -INFINITY);
   f.thrp = nextafterf(tf, -INFINITY);
-  // margins of the behind test
+  return pn;
+}
+// Margins of the behind test (see BehindMargins) for a pixel whose recentred point has length pn, towards
+// lights of |rho| <= rho_max.  Every term is a sum or product of non-negative numbers and FP32 rounding is
+// monotone, so the value at the largest pn of a wavefront is at least the value at each of its pixels: the
+// kernel evaluates the margins once, at that maximum.
+__device__ __forceinline__ BehindMargins behind_margins(const DevScene& S, float pn, float rho_max) {
+  const float e32 = kEps32, up = 1.0f + 1.0e-4f;
+  const float B = S.r2_max * rho_max;
+  const float dh = e32 * (6.0f * pn + 2.0f * S.c_max + 2.0f * B) * 1.01f;
+  const float hmax = pn + S.c_max + B;
+  const float dp = pn * e32 * 1.0001f;              // rounding of the recentred point (as in filter_threshold)
   const float reach = pn * (1.0f + e32) + S.c_max;  // >= |u32| for every sphere
   const float absolute = reach + (float)fabs(S.center[0]) + (float)fabs(S.center[1]) + (float)fabs(S.center[2]);  // >= |p| + |centre| in world coordinates
   const float dd = dp + e32 * S.c_max * 1.01f;      // rounding of the recentred point and of a recentred centre
+  BehindMargins bm;
   bm.q1 = (dp * 1.01f + 1.0e-12f * (absolute + reach)) * up + 1.0e-30f;
   bm.q3 = (dh * 1.01f + dd * (1.0f + rho_max * (2.0f * reach + dd)) * 1.01f +
            1.01f * e32 * (hmax + rho_max * (2.0f * reach * reach + S.r2_max)) +
            1.0e-12f * reach * (1.0f + 2.0f * rho_max * absolute)) * up + 1.0e-30f;
+  return bm;
 }
 constexpr float kTwoKappa = 2.0f * kKappa;
 
@@ -340,7 +358,7 @@ struct Ball {
 };
 __device__ __forceinline__ Ball make_ball(bool live, float x, float y, float z) {
   Ball b;
-  const float n = wave_sum_f(live ? 1.0f : 0.0f);
+  const float n = (float)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live));
   b.any = n > 0.0f;
   const float inv = 1.0f / fmaxf(n, 1.0f);
   b.mx = wave_uniform(wave_sum_f(live ? x : 0.0f) * inv);
@@ -375,7 +393,7 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
     uint32_t occl = 0;
     PixelFilter<KW> f;
     park(f);
-    BehindMargins bm = {0.0f, 0.0f};
+    float pn = 0.0f;  // |recentred point| of a live pixel
     bool live = false;
     if (need) {
       for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
@@ -386,14 +404,9 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
             occl |= 1u << r;
       }
       live = !(occl & 1u);
-      if (live) arm(f, S, p, kb, nb, bm);
+      if (live) pn = arm(f, S, p, kb, nb);
     }
     const RTK_RO float4* ktab = S.k_table + (size_t)batch * S.n_spheres_padded * KV;
-    // the margins of the behind test, over the live pixels of the wavefront (the last factor covers the
-    // FP32 roundings of X and of X + Q2)
-    const float Q1 = wave_max_f(bm.q1);
-    const float Q3 = wave_max_f(bm.q3);
-
     // bundle of the patch; the slack covers the FP32 rounding of points and centres
     const Ball ball = make_ball(live, f.x, f.y, f.z);
     float lgx[KW], lgy[KW], lgz[KW], lrho[KW];
@@ -406,6 +419,12 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
     }
     const float pad = ball.radius + grow * 1.01f +
                       16.0f * kEps32 * (fabsf(ball.mx) + fabsf(ball.my) + fabsf(ball.mz) + ball.radius + S.c_max);
+    // the margins of the behind test at the wavefront's largest |point|: at least every live pixel's own
+    float rho_top = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) rho_top = fmaxf(rho_top, lrho[k]);
+    const BehindMargins bm = behind_margins(S, wave_uniform(wave_max_f(pn)), rho_top);
+    const float Q1 = bm.q1, Q3 = bm.q3;
 
     // rec = {centre, radius} of a sphere (t_extra = 0, growth radius = its own) or of a
     // cluster (t_extra = its radius, growth radius = the scene's largest sphere radius)
@@ -782,7 +801,7 @@ __global__ void __launch_bounds__(64, 5) render_uniform_kernel(DevScene S, DevCa
   V3 color = {0, 0, 0};
   if (px.valid) color = hit ? shade_hit_stashed(S, launder(obj), in_shadow, &stash) : ld3(S.ambient);
   store_patch(C, T, k, quarter, color);
-  const unsigned n_primary = wave_sum(px.valid ? 1u : 0u);
+  const unsigned n_primary = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(px.valid));
   rays = wave_sum(rays);
   n_exact = wave_sum(n_exact);
   if (threadIdx.x == 0) {
@@ -834,7 +853,7 @@ __global__ void __launch_bounds__(kBlock, 3) queue_primary_kernel(DevScene S, De
   }
   sink.flush(B, gridDim.x * kBlock, 1u, s_counts);
   sink.store(B.outs[blockIdx.x * kBlock + threadIdx.x]);
-  const unsigned n_primary = wave_sum(px.valid ? 1u : 0u);
+  const unsigned n_primary = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(px.valid));
   rays = wave_sum(rays);
   n_exact = wave_sum(n_exact);
   if ((threadIdx.x & 63u) == 0) {

@@ -148,7 +148,8 @@ class FilterScene:
     # ---- spheres behind a shadow ray (BehindMargins and the hot loop of shadow_phase_uniform) -------
     def tabulated_behind(self, p, light_xyz):
         """The device drops ray i vs sphere i as 'behind': shadow ray from p [rays,3] towards ONE w = 0
-        light.  Margins per pixel (the device takes their maximum over a wavefront: never smaller)."""
+        light.  Margins per pixel (the device evaluates them once per wavefront, at the largest |pc| of its
+        pixels; every term grows with |pc|, so its margins are never smaller)."""
         p = np.asarray(p, np.float64)
         Lv = np.asarray(light_xyz, np.float64)
         inv = 1.0 / np.sqrt((Lv * Lv).sum())

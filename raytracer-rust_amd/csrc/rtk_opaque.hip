@@ -113,15 +113,17 @@ __device__ __forceinline__ Cone make_cone(float dx, float dy, float dz) {
   // with it -- and this one is within a hundredth of a pixel of the mean direction.
   const float sx = lane_value(dx, 27u) + lane_value(dx, 36u), sy = lane_value(dy, 27u) + lane_value(dy, 36u),
               sz = lane_value(dz, 27u) + lane_value(dz, 36u);
-  const float inv = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz);
+  // square roots and reciprocals are the hardware's (one instruction each, good to an ulp) instead of the
+  // correctly rounded sequences (16 and 10 instructions): the slack below is a hundred ulps wide
+  const float inv = __builtin_amdgcn_rsqf(sx * sx + sy * sy + sz * sz);
   c.ax = wave_uniform(sx * inv), c.ay = wave_uniform(sy * inv), c.az = wave_uniform(sz * inv);
   const float along = dx * c.ax + dy * c.ay + dz * c.az;
   const float qx = dx - along * c.ax, qy = dy - along * c.ay, qz = dz - along * c.az;
-  const float across = sqrtf(qx * qx + qy * qy + qz * qz);
+  const float across = __builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz);
   // the slack covers the FP32 rounding of the directions and of this computation
-  const float t = along > 0.0f ? across / along : 3.0e38f;
+  const float t = along > 0.0f ? across * __builtin_amdgcn_rcpf(along) : 3.0e38f;
   c.tan_t = wave_uniform(wave_max_f(t) * (1.0f + 1.0e-5f) + 2.0e-6f);
-  c.sec_t = wave_uniform(sqrtf(1.0f + c.tan_t * c.tan_t) * (1.0f + 1.0e-6f));
+  c.sec_t = wave_uniform(__builtin_amdgcn_sqrtf(1.0f + c.tan_t * c.tan_t) * (1.0f + 1.0e-6f));
   return c;
 }
 // Can some ray of the cone (apex at the camera) reach the ball {L, Rs}?  With s = L.a and
@@ -324,9 +326,10 @@ __device__ __forceinline__ float arm(PixelFilter<KW>& f, const DevScene& S, V3 p
   const float thr = -((slack + extra) * 1.001f * up + 1.0e-30f);
   const double pp = (double)f.x * f.x + (double)f.y * f.y + (double)f.z * f.z;
   const double t = (double)kKappa * pp + (double)thr;
-  float tf = (float)t;
-  if ((double)tf > t) tf = nextafterf(tf, -INFINITY);
-  f.thrp = nextafterf(tf, -INFINITY);
+  // rounded to nearest and then lowered by at least two ulps (a lower threshold keeps more): below the
+  // next FP32 value under t, which is what the bound needs
+  const float tf = (float)t;
+  f.thrp = tf - __builtin_fmaf(fabsf(tf), 0x1p-22f, 1.0e-30f);
   return pn;
 }
 // Margins of the behind test (see BehindMargins) for a pixel whose recentred point has length pn, towards
@@ -360,12 +363,12 @@ __device__ __forceinline__ Ball make_ball(bool live, float x, float y, float z) 
   Ball b;
   const float n = (float)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live));
   b.any = n > 0.0f;
-  const float inv = 1.0f / fmaxf(n, 1.0f);
+  const float inv = __builtin_amdgcn_rcpf(fmaxf(n, 1.0f));  // any centre will do: the radius below is measured from it
   b.mx = wave_uniform(wave_sum_f(live ? x : 0.0f) * inv);
   b.my = wave_uniform(wave_sum_f(live ? y : 0.0f) * inv);
   b.mz = wave_uniform(wave_sum_f(live ? z : 0.0f) * inv);
   const float ex = x - b.mx, ey = y - b.my, ez = z - b.mz;
-  const float far = live ? sqrtf(ex * ex + ey * ey + ez * ez) : 0.0f;
+  const float far = live ? __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) : 0.0f;  // an ulp: the 1e-5 below covers it
   b.radius = wave_uniform(wave_max_f(far) * (1.0f + 1.0e-5f));
   return b;
 }

@@ -135,7 +135,7 @@ class FilterScene:
         t = float(KAPPA) * pp + thr
         tf = t.astype(F)
         tf = np.where(tf.astype(np.float64) > t, np.nextafter(tf, F(-np.inf)), tf)
-        thrp = np.nextafter(tf, F(-np.inf)).astype(F)
+        thrp = np.nextafter(tf, F(-np.inf)).astype(F)  # the device lowers tf by two ulps or more: never above this
         # hot loop
         two_kappa = F(2.0) * KAPPA
         assert pairwise
@@ -216,18 +216,29 @@ def camera_records(L, radius):
     return np.concatenate([L.astype(F), round_up(Rs)[:, None]], axis=1).astype(F)
 
 
-def make_cone(d):
-    """make_cone of csrc/rtk_opaque.hip for the FP32 directions d [64, 3] of one patch."""
+def ulps(v, k):
+    """v moved by k FP32 steps (the hardware's one-instruction rsq, sqrt and rcp are good to an ulp)."""
+    v = np.asarray(v, F)
+    for _ in range(abs(k)):
+        v = np.nextafter(v, F(np.inf) if k > 0 else F(-np.inf)).astype(F)
+    return v
+
+
+def make_cone(d, inv_ulps=-1):
+    """make_cone of csrc/rtk_opaque.hip for the FP32 directions d [64, 3] of one 8x8 patch (row-major).  The
+    axis lies between the directions of the two pixels either side of the patch's centre; the hardware's
+    square roots and reciprocals are taken an ulp towards the narrower cone (inv_ulps: the axis length either way)."""
     d = d.astype(F)
-    s = d.sum(axis=0, dtype=F)
-    inv = F(1.0) / np.sqrt(F(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]))
+    s = (d[27] + d[36]).astype(F)
+    inv = ulps(F(1.0) / np.sqrt(F(s[0] * s[0] + s[1] * s[1] + s[2] * s[2])), inv_ulps)
     a = (s * inv).astype(F)
     along = (d[:, 0] * a[0] + d[:, 1] * a[1] + d[:, 2] * a[2]).astype(F)
     q = (d - along[:, None] * a[None, :]).astype(F)
-    across = np.sqrt((q * q).sum(axis=1, dtype=F)).astype(F)
-    t = np.where(along > 0, across / np.where(along > 0, along, F(1)), F(3.0e38)).astype(F)
+    across = ulps(np.sqrt((q * q).sum(axis=1, dtype=F)).astype(F), -1)
+    rcp = ulps((F(1.0) / np.where(along > 0, along, F(1))).astype(F), -1)
+    t = np.where(along > 0, (across * rcp).astype(F), F(3.0e38)).astype(F)
     tan_t = F(t.max() * F(1.0 + 1.0e-5) + F(2.0e-6))
-    sec_t = F(np.sqrt(F(1.0) + tan_t * tan_t) * F(1.0 + 1.0e-6))
+    sec_t = F(ulps(np.sqrt(F(1.0) + tan_t * tan_t), -1) * F(1.0 + 1.0e-6))
     return a, tan_t, sec_t
 
 
@@ -247,7 +258,7 @@ def make_ball(pts):
     inv = F(1.0) / n
     m = (pts.sum(axis=0, dtype=F) * inv).astype(F)
     e = (pts - m).astype(F)
-    far = np.sqrt((e * e).sum(axis=1, dtype=F)).astype(F)
+    far = ulps(np.sqrt((e * e).sum(axis=1, dtype=F)).astype(F), -1)  # the hardware's square root, an ulp short
     return m, F(far.max() * F(1.0 + 1.0e-5))
 
 

@@ -212,6 +212,7 @@ def test_cone_test_keeps_every_sphere_some_ray_of_the_patch_grazes(scale):
             fs = FilterScene(c, R)
             spheres = camera_records(c - origin, R)
             assert not (hit & ~cone_reaches(cone, spheres)).any(), (trial, delta)
+            assert not (hit & ~cone_reaches(make_cone(d.astype(np.float32), inv_ulps=1), spheres)).any(), (trial, delta)
             balls = sphere_balls(fs)
             cl = cluster_balls(balls[:, :3], balls[:, 3])
             Lc = cl[:, :3].astype(np.float64) + fs.center - origin

@@ -430,22 +430,30 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
     const float Q1 = bm.q1, Q3 = bm.q3;
 
     // rec = {centre, radius} of a sphere (t_extra = 0, growth radius = its own) or of a
-    // cluster (t_extra = its radius, growth radius = the scene's largest sphere radius)
+    // cluster (t_extra = its radius, growth radius = the scene's largest sphere radius).
+    // The squared distance of the centre from the line along g_k through m is formed as |u|^2 - s^2: one
+    // multiply-add per light instead of six for |u - s g_k|^2.  That difference carries the roundings of
+    // |u|^2 and of s and the length of the rounded g_k to first order, 13 eps |u|^2 at most; `room` allows
+    // 32.  The factors that cover the roundings of t and of the reach are folded into the per-light
+    // constant and into the reach (each part of rr stays inflated by more than its own roundings), and a
+    // record passes no light when its reach is negative (padding records), so that is tested once.
+    float lgrow[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) lgrow[k] = lrho[k] * ((1.0f + 8.0f * kEps32) * (1.0f + 4.0f * kEps32) * (1.0f + 4.0f * kEps32));
     auto lines_reach = [&](float4 rec, float t_extra, float r_grow) {
       const float ux = ball.mx - rec.x, uy = ball.my - rec.y, uz = ball.mz - rec.z;
-      const float reach = rec.w + pad;  // R + rho_w + slack
+      const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+      const float reach = (rec.w + pad) * (1.0f + 4.0f * kEps32);  // R + rho_w + slack
       const float tb = ball.radius + t_extra;
-      bool pass = false;
+      float best = -3.0e38f;  // max over the lights of rr^2 - (|u|^2 - s^2)
 #pragma unroll
       for (int k = 0; k < KW; ++k) {
         const float s = __builtin_fmaf(uz, lgz[k], __builtin_fmaf(uy, lgy[k], ux * lgx[k]));
-        const float qx = __builtin_fmaf(-s, lgx[k], ux), qy = __builtin_fmaf(-s, lgy[k], uy), qz = __builtin_fmaf(-s, lgz[k], uz);
-        const float d2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
-        const float t = fmaxf(tb - s, 0.0f) * (1.0f + 8.0f * kEps32);
-        const float rr = __builtin_fmaf(t, r_grow * lrho[k], reach) * (1.0f + 4.0f * kEps32);
-        pass |= rr >= 0.0f && __builtin_fmaf(rr, rr, -d2) >= 0.0f;
+        const float t = fmaxf(tb - s, 0.0f);
+        const float rr = __builtin_fmaf(t, r_grow * lgrow[k], reach);
+        best = fmaxf(best, __builtin_fmaf(rr, rr, __builtin_fmaf(s, s, -uu)));
       }
-      return pass;
+      return reach >= 0.0f && __builtin_fmaf(uu, 32.0f * kEps32, best) >= 0.0f;
     };
 
     bool wave_live = wave_any(live);

@@ -279,17 +279,20 @@ def lines_reach(fs, ball, lights_xyz, rec, cluster):
     t_extra = rec[:, 3] if cluster else F(0)
     r_grow = fs.r_max if cluster else rec[:, 3]
     ux, uy, uz = (m[0] - rec[:, 0]).astype(F), (m[1] - rec[:, 1]).astype(F), (m[2] - rec[:, 2]).astype(F)
-    reach = (rec[:, 3] + pad).astype(F)
+    e4 = F(F(1.0) + F(4.0) * EPS32)
+    fold = F(F(F(F(1.0) + F(8.0) * EPS32) * e4) * e4)
+    uu = fma(uz, uz, fma(uy, uy, (ux * ux).astype(F)))
+    reach = ((rec[:, 3] + pad).astype(F) * e4).astype(F)
     tb = (radius + t_extra).astype(F) if cluster else F(radius)
-    ok = np.zeros(len(rec), bool)
+    best = np.full(len(rec), F(-3.0e38), F)
     for k in range(len(Lv)):
+        # squared distance from the line as |u|^2 - s^2 (one multiply-add per light); its first-order roundings
+        # are covered by 32 eps |u|^2 below
         s = fma(uz, g[k, 2], fma(uy, g[k, 1], (ux * g[k, 0]).astype(F)))
-        qx, qy, qz = fma(-s, g[k, 0], ux), fma(-s, g[k, 1], uy), fma(-s, g[k, 2], uz)
-        d2 = fma(qz, qz, fma(qy, qy, (qx * qx).astype(F)))
-        t = (np.maximum((tb - s).astype(F), F(0)) * F(1.0 + 8.0 * float(EPS32))).astype(F)
-        rr = (fma(t, (r_grow * lrho[k]).astype(F), reach) * F(1.0 + 4.0 * float(EPS32))).astype(F)
-        ok |= (rr >= 0) & (fma(rr, rr, -d2) >= 0)
-    return ok
+        t = np.maximum((tb - s).astype(F), F(0))
+        rr = fma(t, (r_grow * F(lrho[k] * fold)).astype(F), reach)
+        best = np.maximum(best, fma(rr, rr, fma(s, s, -uu)))
+    return (reach >= 0) & (fma(uu, F(32.0) * EPS32, best) >= 0)
 
 
 # ---- per-ray cluster tests of the one-ray-per-lane sweeps (csrc/rtk_sweeps.h) ------------------

@@ -334,6 +334,32 @@ def _field_camera(rtk, extent, w, h, eye=None, to=None):
     return camera
 
 
+@pytest.mark.parametrize("glass", [False, True])
+def test_shininess_of_every_kind(rtk, dev, oracle, glass):
+    """`reflect_dot_eye.powf(shininess)` (src/scene/lighting.rs:143-147): integer exponents from 1 to 4095 go through
+    the kernels' squaring-and-multiplying power, everything else (fractions, 0, 4096 and more) through the
+    library's pow.  Black and coloured spheres (a black channel keeps even the faintest highlight alive), every
+    exponent kind in one scene, opaque (fused kernel) and with mirrors among them (the ray-tree kernels)."""
+    rng = np.random.default_rng(77 if glass else 76)
+    M = rtk.Matrix4x4
+    E = 12.0
+    scene = rtk.Scene()
+    for pos in (rtk.vec3(-0.8 * E, 1.5 * E, -0.5 * E), rtk.vec3(0.9 * E, 1.1 * E, 0.3 * E)):
+        scene.add_light(rtk.PointLight(pos, rtk.rgb(0.6, 0.5, 0.7)))
+    mat = rtk.Material.default()
+    scene.add_object(rtk.Plane().with_material(mat.with_color(rtk.rgb(0.0, 0.3, 0.0)).with_shininess(33.3)))
+    kinds = [1.0, 2.0, 3.0, 7.0, 10.0, 200.0, 255.0, 256.0, 1000.0, 4095.0, 4096.0, 10000.0, 0.0, 0.5, 33.3, 199.999]
+    for i in range(170):
+        r = float(rng.uniform(0.4, 1.6))
+        c = (rng.uniform(-E, E), rng.uniform(0.3, 0.4 * E), rng.uniform(0.0, 2 * E))
+        col = rtk.rgb(0.0, 0.0, 0.0) if i % 3 == 0 else rtk.rgb(*rng.uniform(0.0, 1.0, size=3))
+        m = mat.with_color(col).with_shininess(kinds[i % len(kinds)]).with_specular(float(rng.choice([0.9, 0.3])))
+        if glass and i % 5 == 0:
+            m = m.with_reflective(0.6)  # mirrors: secondary rays without the reference's unbounded Schlick term
+        scene.add_object(rtk.Sphere().with_material(m).with_transform(M.translate(*c) * M.scale(r, r, r)))
+    check_against_oracle(dev, oracle, scene, _field_camera(rtk, E, 256, 144), f"shininess kinds, glass={glass}")
+
+
 @pytest.mark.parametrize("seed,affine", [(1, False), (2, True), (3, True)])
 def test_clustered_fields_w0_lights(rtk, dev, oracle, seed, affine):
     """Several hundred overlapping spheres of very different sizes (many clusters, large r_max

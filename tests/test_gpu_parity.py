@@ -339,7 +339,8 @@ def test_shininess_of_every_kind(rtk, dev, oracle, glass):
     """`reflect_dot_eye.powf(shininess)` (src/scene/lighting.rs:143-147): integer exponents from 1 to 4095 go through
     the kernels' squaring-and-multiplying power, everything else (fractions, 0, 4096 and more) through the
     library's pow.  Black and coloured spheres (a black channel keeps even the faintest highlight alive), every
-    exponent kind in one scene, opaque (fused kernel) and with mirrors among them (the ray-tree kernels)."""
+    exponent kind in one scene, opaque (fused kernel) and with mirrors and glass among them (the ray-tree kernels; a few glass pixels
+    there exceed the FP32 range on both sides, which the comparison counts as equal)."""
     rng = np.random.default_rng(77 if glass else 76)
     M = rtk.Matrix4x4
     E = 12.0
@@ -355,7 +356,7 @@ def test_shininess_of_every_kind(rtk, dev, oracle, glass):
         col = rtk.rgb(0.0, 0.0, 0.0) if i % 3 == 0 else rtk.rgb(*rng.uniform(0.0, 1.0, size=3))
         m = mat.with_color(col).with_shininess(kinds[i % len(kinds)]).with_specular(float(rng.choice([0.9, 0.3])))
         if glass and i % 5 == 0:
-            m = m.with_reflective(0.6)  # mirrors: secondary rays without the reference's unbounded Schlick term
+            m = m.with_transparency(0.8).with_reflective(0.6).with_refractivity(1.5) if i % 10 == 0 else m.with_reflective(0.6)
         scene.add_object(rtk.Sphere().with_material(m).with_transform(M.translate(*c) * M.scale(r, r, r)))
     check_against_oracle(dev, oracle, scene, _field_camera(rtk, E, 256, 144), f"shininess kinds, glass={glass}")
 

@@ -13,7 +13,7 @@ constexpr int kGroup = 8;        // records per wavefront early-out branch (one 
 constexpr int kBundle = 64;      // records per wavefront-level test (one sphere per lane); arrays are padded to this
 constexpr int kSuper = 8;        // clusters of kBundle spheres per ball of the upper level
 constexpr int kMaxDepth = 8;     // == RTK_MAX_DEPTH_LIMIT
-constexpr uint32_t kMaxLights = 32767;  // == RTK_MAX_LIGHTS: the shadow-ray count of a hit is kept in 15 bits
+constexpr uint32_t kMaxLights = 32767;  // == RTK_MAX_LIGHTS
 
 constexpr float kEps32 = 5.9604645e-8f;  // 2^-24, unit round-off of FP32
 
@@ -182,7 +182,7 @@ struct WavefrontBuffers {
 struct OpaqueBuffers {
   uint32_t* hit_obj;  // object index of the closest hit, 0xffffffff = miss
   double* hit_t;      // its ray parameter
-  uint16_t* shadow;   // bit 15: in shadow; bits 0..14: shadow rays the reference traces for this hit
+  uint16_t* shadow;   // 1: the hit is in shadow (the shadow-ray kernel counts its rays itself)
 };
 
 struct RenderTarget {

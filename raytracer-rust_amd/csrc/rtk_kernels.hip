@@ -95,18 +95,10 @@ __global__ void __launch_bounds__(64, 4) render_small_kernel(DevScene S, DevCame
   const bool valid = x < C.width && y < C.height;
   const V3 origin = ld3(C.origin);
   const V3 dir = camera_ray_direction(C, x, y);  // cameras.rs:52-69
-  unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
-  V3 color = trace_ray<true, false, 1, false, true, TRACK>(S, nullptr, nullptr, valid, origin, dir, c_primary, c_shadow, c_secondary, c_exact);
+  WaveCount wc;
+  V3 color = trace_ray<true, false, 1, false, true, TRACK>(S, nullptr, nullptr, valid, origin, dir, wc);
   store_patch(C, T, k, pg.quarter, color);
-  c_primary = wave_sum(c_primary);
-  c_shadow = wave_sum(c_shadow);
-  c_secondary = wave_sum(c_secondary);
-  if (lane == 0) {
-    DevCounters* mine = counters + (pg.tile % kCounterShards);
-    atomicAdd(&mine->rays_primary, (unsigned long long)c_primary);
-    atomicAdd(&mine->rays_shadow, (unsigned long long)c_shadow);
-    atomicAdd(&mine->rays_secondary, (unsigned long long)c_secondary);
-  }
+  flush_counts(counters + (pg.tile % kCounterShards), wc);
 }
 
 template <int LB, bool WIDE, bool TRACK>
@@ -125,7 +117,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera
   uint32_t my_patch = 0, my_slot = 0;     // ... this one
   uint32_t cur_patch = 0, cur_next = 64;  // the wavefront's current patch and its next unassigned pixel
   bool exhausted = false;                 // the launch has no patches left
-  unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
+  WaveCount wc;
 
   for (;;) {
     // pixels for the idle lanes
@@ -184,8 +176,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera
     }
     if (__any(have)) {
       StackSink sink{stack, sp, color};
-      trace_step<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, weight, depth, sink, c_primary,
-                                                      c_shadow, c_secondary, c_exact);
+      trace_step<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, weight, depth, sink, wc);
     }
 
     // pixels whose tree is done
@@ -195,17 +186,8 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(DevScene S, DevCamera
     }
   }
 
-  // ray counters: one atomic per wavefront
-  c_primary = wave_sum(c_primary);
-  c_shadow = wave_sum(c_shadow);
-  c_secondary = wave_sum(c_secondary);
-  c_exact = wave_sum(c_exact);
-  if (lane == 0) {
-    atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)c_primary);
-    atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)c_shadow);
-    atomicAdd(&counter_shard(counters)->rays_secondary, (unsigned long long)c_secondary);
-    atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)c_exact);
-  }
+  // ray counters: one set of atomics per wavefront
+  flush_counts(counter_shard(counters), wc);
 }
 
 // `Scene::trace` for caller-supplied rays (src/scene.rs:136-138): n x 4 doubles each.
@@ -220,23 +202,14 @@ __global__ void __launch_bounds__(kBlock) trace_rays_kernel(DevScene S, const do
     o = ld3(origins + 4 * i);
     d = ld3(directions + 4 * i);
   }
-  unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
-  V3 color = trace_ray<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, valid, o, d, c_primary, c_shadow, c_secondary, c_exact);
+  WaveCount wc;
+  V3 color = trace_ray<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, valid, o, d, wc);
   if (valid) {
     colors[3 * i + 0] = color.x;
     colors[3 * i + 1] = color.y;
     colors[3 * i + 2] = color.z;
   }
-  c_primary = wave_sum(c_primary);
-  c_shadow = wave_sum(c_shadow);
-  c_secondary = wave_sum(c_secondary);
-  c_exact = wave_sum(c_exact);
-  if ((threadIdx.x & 63u) == 0) {
-    atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)c_primary);
-    atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)c_shadow);
-    atomicAdd(&counter_shard(counters)->rays_secondary, (unsigned long long)c_secondary);
-    atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)c_exact);
-  }
+  flush_counts(counter_shard(counters), wc);
 }
 
 // Per-camera records of the camera-ray tests: one thread per (padded) sphere.

@@ -143,7 +143,7 @@ template <typename StashT = Stash>
 __device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera& C, const float4* __restrict__ prim,
                                               const float4* __restrict__ prim_ball,
                                               const float4* __restrict__ prim_cluster, const PixelRef& px, Closest& best,
-                                              unsigned& n_exact, StashT* stash = nullptr) {
+                                              WaveCount& wc, StashT* stash = nullptr) {
   const V3 origin = ld3(C.origin);
   const uint32_t lane = threadIdx.x & 63u;
   closest_init(best);
@@ -177,10 +177,11 @@ __device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera
         t = __builtin_fmaf(r.y, dy, t);
         t = __builtin_fmaf(r.z, dz, t);
         const bool pass = px.valid && __builtin_fmaf(t, t, -r.w) >= 0.0f;
-        if (wave_any(pass)) {
+        const unsigned n_pass = lanes_where(pass);
+        if (n_pass) {
+          wc.exact += n_pass;
           const RTK_RO SphRecord& rec = S.sph_record[j];
           if (pass) {
-            ++n_exact;
             double t0, t1;
             const V3 d = stash ? get3(stash->dir) : camera_ray_direction(C, launder(px.x), px.y);
             if (intersect_sphere_record(S, rec, origin, d, 0.0, t0, t1)) {
@@ -202,16 +203,12 @@ __global__ void __launch_bounds__(kBlock, 4) primary_kernel(DevScene S, DevCamer
                                                            OpaqueBuffers B, DevCounters* counters) {
   const PixelRef px = pixel_ref(T, C, T.n_local_tiles - 1u - blockIdx.x);
   Closest best;
-  unsigned n_exact = 0;
-  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, n_exact);
+  WaveCount wc;
+  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, wc);
   B.hit_obj[px.local] = px.valid ? best.obj : 0xffffffffu;
   B.hit_t[px.local] = best.t;
-  const unsigned n_primary = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(px.valid));
-  n_exact = wave_sum(n_exact);
-  if ((threadIdx.x & 63u) == 0) {
-    atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)n_primary);
-    atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
-  }
+  wc.primary = lanes_where(px.valid);
+  flush_counts(counter_shard(counters), wc);
 }
 
 // The shading point of a recorded hit: `over_position` of LightingData (src/scene/lighting.rs:50).
@@ -385,10 +382,9 @@ __device__ __forceinline__ Ball make_ball(bool live, float x, float y, float z) 
 // members' balls the same holds with R -> Rc in the reach, s_m -> s_m - Rc, and the growth
 // terms taken with the scene's largest sphere radius.
 template <int KW>
-__device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool need, V3 p, unsigned& n_rays, unsigned& n_exact) {
+__device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool need, V3 p, WaveCount& wc) {
   constexpr int KV = KW / 4;  // float4 per table row
   const uint32_t lane = threadIdx.x & 63u;
-  unsigned rays = 0;
   bool in_shadow = false;
   for (uint32_t kb = 0, batch = 0; kb < S.n_lights; kb += KW, ++batch) {
     if (!wave_any(need)) break;
@@ -496,12 +492,12 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
           mask &= ~occl;
           if (wave_any(mask != 0)) {
             const RTK_RO SphRecord& rec = S.sph_record[j];
-            if (mask) {
-              for (uint32_t r = 0; r < nb; ++r)
-                if ((mask >> r) & 1u) {
-                  ++n_exact;
-                  if (shadow_ray_blocked(S, rec, S.lights[kb + r], p)) occl |= 1u << r;
-                }
+            for (uint32_t r = 0; r < nb; ++r) {  // one light after the other, for the lanes that kept it
+              const bool run = ((mask >> r) & 1u) != 0u;
+              const unsigned n_run = lanes_where(run);
+              if (n_run == 0u) continue;
+              wc.exact += n_run;
+              if (run && shadow_ray_blocked(S, rec, S.lights[kb + r], p)) occl |= 1u << r;
             }
             changed = true;
           }
@@ -516,18 +512,20 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
         }
       }
     }
+    // the reference stops at the first blocked light (src/scene.rs:208-225): a pixel traces the lights
+    // of the batch up to and including that one
+    unsigned traced = 0;
     if (need) {
       occl &= (nb >= 32u) ? 0xffffffffu : ((1u << nb) - 1u);
+      traced = nb;
       if (occl) {
-        rays += (unsigned)__builtin_ctz(occl) + 1u;
+        traced = (unsigned)__builtin_ctz(occl) + 1u;
         in_shadow = true;
         need = false;
-      } else {
-        rays += nb;
       }
     }
+    wc.shadow += lanes_total<bits_for(KW)>(traced);
   }
-  n_rays += rays;
   return in_shadow;
 }
 
@@ -543,11 +541,10 @@ __global__ void __launch_bounds__(kBlock, 4) shadow_general_kernel(DevScene S, D
   const bool hit = obj != 0xffffffffu;
   V3 p = {0, 0, 0};
   if (hit) p = over_point(S, C, px, obj, B.hit_t[px.local]);
-  unsigned rays = 0, n_exact = 0;
-  const bool in_shadow = shadow_sweeps<LB, false>(S, hit, p, rays, n_exact);
-  B.shadow[px.local] = (uint16_t)((in_shadow ? 0x8000u : 0u) | rays);
-  n_exact = wave_sum(n_exact);
-  if ((threadIdx.x & 63u) == 0) atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)n_exact);
+  WaveCount wc;
+  const bool in_shadow = shadow_sweeps<LB, false>(S, hit, p, wc);
+  B.shadow[px.local] = in_shadow ? 1u : 0u;
+  flush_counts(counter_shard(counters), wc);
 }
 
 // ------------------------------------------------------------------------------------
@@ -557,9 +554,8 @@ __global__ void __launch_bounds__(kBlock, 4) shadow_general_kernel(DevScene S, D
 // in place of the camera).  Level 2 uses the general per-ray form with the line direction
 // rebuilt per lane: g = L/|L| for w == 0, (L - p)/|L - p| for w == 1 (rho = 0).
 template <int KW>
-__device__ __forceinline__ bool shadow_phase_bundled(const DevScene& S, bool need, V3 p, unsigned& n_rays, unsigned& n_exact) {
+__device__ __forceinline__ bool shadow_phase_bundled(const DevScene& S, bool need, V3 p, WaveCount& wc) {
   const uint32_t lane = threadIdx.x & 63u;
-  unsigned rays = 0;
   bool in_shadow = false;
   for (uint32_t kb = 0; kb < S.n_lights; kb += KW) {
     if (!wave_any(need)) break;
@@ -689,12 +685,12 @@ __device__ __forceinline__ bool shadow_phase_bundled(const DevScene& S, bool nee
           mask &= ~occl;
           if (wave_any(mask != 0)) {
             const RTK_RO SphRecord& rec = S.sph_record[j];
-            if (mask) {
-              for (uint32_t r = 0; r < nb; ++r)
-                if ((mask >> r) & 1u) {
-                  ++n_exact;
-                  if (shadow_ray_blocked(S, rec, S.lights[kb + r], p)) occl |= 1u << r;
-                }
+            for (uint32_t r = 0; r < nb; ++r) {  // one light after the other, for the lanes that kept it
+              const bool run = ((mask >> r) & 1u) != 0u;
+              const unsigned n_run = lanes_where(run);
+              if (n_run == 0u) continue;
+              wc.exact += n_run;
+              if (run && shadow_ray_blocked(S, rec, S.lights[kb + r], p)) occl |= 1u << r;
             }
             changed = true;
           }
@@ -705,18 +701,20 @@ __device__ __forceinline__ bool shadow_phase_bundled(const DevScene& S, bool nee
         }
       }
     }
+    // the reference stops at the first blocked light (src/scene.rs:208-225): a pixel traces the lights
+    // of the batch up to and including that one
+    unsigned traced = 0;
     if (need) {
       occl &= (nb >= 32u) ? 0xffffffffu : ((1u << nb) - 1u);
+      traced = nb;
       if (occl) {
-        rays += (unsigned)__builtin_ctz(occl) + 1u;
+        traced = (unsigned)__builtin_ctz(occl) + 1u;
         in_shadow = true;
         need = false;
-      } else {
-        rays += nb;
       }
     }
+    wc.shadow += lanes_total<bits_for(KW)>(traced);
   }
-  n_rays += rays;
   return in_shadow;
 }
 
@@ -743,19 +741,12 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DevScene S, DevCamera C, 
   const uint32_t k = blockIdx.x;
   const PixelRef px = pixel_ref(T, C, k);
   V3 color = {0, 0, 0};
-  unsigned n_shadow = 0;
   if (px.valid) {
     color = ld3(S.ambient);  // a miss, or trace_inner at depth >= MAX_DEPTH, returns ambient_color
     const uint32_t obj = B.hit_obj[px.local];
-    if (obj != 0xffffffffu) {
-      const uint16_t sh = B.shadow[px.local];
-      n_shadow = sh & 0x7fffu;
-      color = shade_hit(S, C, px, obj, B.hit_t[px.local], (sh & 0x8000u) != 0);
-    }
+    if (obj != 0xffffffffu) color = shade_hit(S, C, px, obj, B.hit_t[px.local], B.shadow[px.local] != 0u);
   }
   store_tile(C, T, k, color, s_rgb, s_px);
-  n_shadow = wave_sum(n_shadow);
-  if ((threadIdx.x & 63u) == 0) atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)n_shadow);
 }
 
 // `apply_lighting` for the fused kernel: the hit geometry comes back from the stash
@@ -795,8 +786,9 @@ __global__ void __launch_bounds__(64, 5) render_uniform_kernel(DevScene S, DevCa
   const uint32_t k = T.n_local_tiles - 1u - tile;  // expensive tiles (bottom of the frame) first
   const PixelRef px = pixel_ref(T, C, k, quarter, threadIdx.x);
   Closest best;
-  unsigned n_exact = 0;
-  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, n_exact, &stash);
+  WaveCount wc;
+  wc.primary = lanes_where(px.valid);
+  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, wc, &stash);
   const uint32_t obj = px.valid ? best.obj : 0xffffffffu;
   const bool hit = obj != 0xffffffffu;
   V3 p = {0, 0, 0};
@@ -806,21 +798,11 @@ __global__ void __launch_bounds__(64, 5) render_uniform_kernel(DevScene S, DevCa
     put3(stash.normal, g.normal);
     p = g.over;
   }
-  unsigned rays = 0;
-  const bool in_shadow = TABULATED ? shadow_phase_uniform<KW>(S, hit, p, rays, n_exact)
-                                   : shadow_phase_bundled<KW>(S, hit, p, rays, n_exact);
+  const bool in_shadow = TABULATED ? shadow_phase_uniform<KW>(S, hit, p, wc) : shadow_phase_bundled<KW>(S, hit, p, wc);
   V3 color = {0, 0, 0};
   if (px.valid) color = hit ? shade_hit_stashed(S, launder(obj), in_shadow, &stash) : ld3(S.ambient);
   store_patch(C, T, k, quarter, color);
-  const unsigned n_primary = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(px.valid));
-  rays = wave_sum(rays);
-  n_exact = wave_sum(n_exact);
-  if (threadIdx.x == 0) {
-    DevCounters* mine = counters + (tile % kCounterShards);
-    atomicAdd(&mine->rays_primary, (unsigned long long)n_primary);
-    atomicAdd(&mine->rays_shadow, (unsigned long long)rays);
-    atomicAdd(&mine->exact_tests, (unsigned long long)n_exact);
-  }
+  flush_counts(counters + (tile % kCounterShards), wc);
 }
 
 // Level 0 of the level-by-level order (rtk_wavefront.hip) on the bundle tests of the fused kernel:
@@ -840,8 +822,9 @@ __global__ void __launch_bounds__(kBlock, 3) queue_primary_kernel(DevScene S, De
   __shared__ uint32_t s_counts[10];
   const PixelRef px = pixel_ref(T, C, tile_base + blockIdx.x);
   Closest best;
-  unsigned n_exact = 0;
-  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, n_exact, &stash);
+  WaveCount wc;
+  wc.primary = lanes_where(px.valid);
+  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, wc, &stash);
   const uint32_t obj = px.valid ? best.obj : 0xffffffffu;
   const bool hit = obj != 0xffffffffu;
   ParkSink sink(s_park);
@@ -854,8 +837,7 @@ __global__ void __launch_bounds__(kBlock, 3) queue_primary_kernel(DevScene S, De
     p = g.over;
     emit_children(S, ob, g, 1.0, 1.0, 0, sink);  // children first: nothing of them stays live across the shadow phase
   }
-  unsigned rays = 0;
-  const bool in_shadow = shadow_phase_uniform<KW>(S, hit, p, rays, n_exact);
+  const bool in_shadow = shadow_phase_uniform<KW>(S, hit, p, wc);
   if (px.valid) {
     if (hit)
       sink.term(shade_hit_stashed(S, launder(obj), in_shadow, &stash), 1.0);
@@ -864,14 +846,7 @@ __global__ void __launch_bounds__(kBlock, 3) queue_primary_kernel(DevScene S, De
   }
   sink.flush(B, gridDim.x * kBlock, 1u, s_counts);
   sink.store(B.outs[blockIdx.x * kBlock + threadIdx.x]);
-  const unsigned n_primary = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(px.valid));
-  rays = wave_sum(rays);
-  n_exact = wave_sum(n_exact);
-  if ((threadIdx.x & 63u) == 0) {
-    atomicAdd(&counter_shard(B.counters)->rays_primary, (unsigned long long)n_primary);
-    atomicAdd(&counter_shard(B.counters)->rays_shadow, (unsigned long long)rays);
-    atomicAdd(&counter_shard(B.counters)->exact_tests, (unsigned long long)n_exact);
-  }
+  flush_counts(counter_shard(B.counters), wc);
 }
 
 bool queue_primary_bundled_applies(const DevScene& S) { return S.lights_uniform && !S.track_n1 && S.max_depth >= 2; }

@@ -440,8 +440,41 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 __device__ __forceinline__ float wave_max_f(float v) {
   return wave_reduce(v, -3.0e38f, [](float a, float b) { return fmaxf(a, b); });
 }
-__device__ __forceinline__ unsigned wave_sum(unsigned v) {
-  return wave_reduce(v, 0u, [](unsigned a, unsigned b) { return a + b; });
+
+// Ray and test counts of one wavefront.  The numbers are wavefront-uniform (they live in scalar
+// registers): a site adds the NUMBER OF LANES for which its predicate holds -- a ballot and a
+// population count -- instead of every lane incrementing a register of its own that is summed over
+// the lanes at the end.  A lane that never took part (a pixel outside the frame, a node slot without
+// a node, a lane masked off around the site) contributes nothing by construction, whatever its
+// vector registers or spill slots hold.  Every addition must stand in wavefront-uniform control flow
+// (the predicate carries the per-lane condition), or the sum would differ from lane to lane.
+struct WaveCount {
+  unsigned primary = 0, shadow = 0, secondary = 0, exact = 0;
+};
+__device__ __forceinline__ unsigned lanes_where(bool p) { return (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
+// Sum over the lanes of a small per-lane amount (< 2^BITS; 0 for lanes that do not take part):
+// one ballot per bit.
+template <int BITS>
+__device__ __forceinline__ unsigned lanes_total(unsigned amount) {
+  unsigned total = 0;
+#pragma unroll
+  for (int b = 0; b < BITS; ++b) total += lanes_where(((amount >> b) & 1u) != 0u) << b;
+  return total;
+}
+// bits needed for an amount of at most n
+constexpr int bits_for(unsigned n) {
+  int b = 0;
+  for (; n != 0u; n >>= 1) ++b;
+  return b;
+}
+// One lane of the wavefront adds the counts to its shard of the launch's counters.
+__device__ __forceinline__ void flush_counts(DevCounters* shard, const WaveCount& c) {
+  if ((threadIdx.x & 63u) == 0) {
+    if (c.primary) atomicAdd(&shard->rays_primary, (unsigned long long)c.primary);
+    if (c.shadow) atomicAdd(&shard->rays_shadow, (unsigned long long)c.shadow);
+    if (c.secondary) atomicAdd(&shard->rays_secondary, (unsigned long long)c.secondary);
+    if (c.exact) atomicAdd(&shard->exact_tests, (unsigned long long)c.exact);
+  }
 }
 
 

@@ -33,7 +33,7 @@ constexpr int kTransposeBelow = 24;
 template <typename ExactFn>
 __device__ __forceinline__ void sweep_primary(const DevScene& S, const float4* __restrict__ prim,
                                               const float4* __restrict__ prim_cluster, bool active, float dx, float dy, float dz,
-                                              ExactFn&& exact) {
+                                              WaveCount& wc, ExactFn&& exact) {
   if (!__any(active)) return;
   for (uint32_t first = 0; first < S.n_spheres_grouped; first += kBundle) {
     const float4 cl = prim_cluster[first / kBundle];
@@ -64,7 +64,9 @@ __device__ __forceinline__ void sweep_primary(const DevScene& S, const float4* _
           t = __builtin_fmaf(r.y, dy, t);
           t = __builtin_fmaf(r.z, dz, t);
           bool pass = reach && (__builtin_fmaf(t, t, -r.w) >= 0.0f);
-          if (__any(pass)) {
+          const unsigned n_pass = lanes_where(pass);
+          if (n_pass) {
+            wc.exact += n_pass;
             uint32_t obj = S.sph_object[j + g];
             if (pass) exact(obj);
           }
@@ -89,10 +91,12 @@ __device__ __forceinline__ void sweep_primary(const DevScene& S, const float4* _
 //     dist(C, line) <= Rc + r_max |rho| max(Rc - s_C, 0) + r_max^3 rho^2 / 2
 // is necessary for any member to be touched (r_max = largest sphere radius of the scene).  The same
 // holds for any ball that contains the members' balls: the balls of whole groups of clusters.
+// exact(slot, mask) runs the f64 tests of one lane's candidate and returns how many it ran (at most
+// NR); the sweep adds them to wc.exact.
 template <int NR, bool WIDE, typename ExactFn, typename DoneFn>
 __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, float px, float py, float pz,
                                              const float (&gx)[NR], const float (&gy)[NR], const float (&gz)[NR],
-                                             const float (&rho)[NR], float thr, ExactFn&& exact, DoneFn&& done,
+                                             const float (&rho)[NR], float thr, WaveCount& wc, ExactFn&& exact, DoneFn&& done,
                                              bool forward = false) {
   // forward: only hits at positive ray parameters matter to the caller (NR == 1, rho == 0): a
   // cluster that lies entirely behind the origin is not opened
@@ -168,6 +172,7 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
         }
         // every lane now works through its own candidates; lanes run different spheres side by side
         while (__any(cand != 0ull)) {
+          unsigned ran = 0;
           if (cand != 0ull) {
             const uint32_t b = (uint32_t)__builtin_ctzll(cand);
             cand &= cand - 1ull;
@@ -184,9 +189,10 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
                 if (__builtin_fmaf(h, h, -cf) >= thr) mask |= 1u << r;
               }
             }
-            if (mask) exact(first + b, mask);
+            if (mask) ran = exact(first + b, mask);
             if (active && done()) active = false, cand = 0ull;
           }
+          wc.exact += lanes_total<bits_for(NR)>(ran);
         }
         wave_live = __any(active);
         continue;
@@ -209,6 +215,7 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
           }
         }
         if (__any(reach && m >= thr)) {
+          unsigned ran = 0;  // exact tests of this lane over the group
 #pragma unroll 1
           for (int g = 0; g < kGroup; ++g) {
             float4 c = S.sph_filter[j + g];
@@ -222,8 +229,9 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
               if (__builtin_fmaf(h, h, -cf) >= thr) mask |= 1u << r;
             }
             if (!reach) mask = 0;
-            if (mask) exact(j + g, mask);
+            if (mask) ran += exact(j + g, mask);
           }
+          wc.exact += lanes_total<bits_for(NR * kGroup)>(ran);
           // lanes that need no further test drop out; the wavefront stops once all have
           if (active && done()) active = false, reach = false;
           wave_live = __any(active);
@@ -239,10 +247,8 @@ __device__ __forceinline__ void sweep_filter(const DevScene& S, bool& active, fl
 // Lights are swept in batches of LB fused rays; the reference stops at the first blocked
 // light, so `n_rays` = index of the first blocked light + 1 (or the light count).
 template <int LB, bool WIDE>
-__device__ __forceinline__ bool shadow_by_sweeps(const DevScene& S, bool active, V3 p, unsigned& n_rays,
-                                                 unsigned& n_exact) {
+__device__ __forceinline__ bool shadow_by_sweeps(const DevScene& S, bool active, V3 p, WaveCount& wc) {
   bool in_shadow = false;
-  unsigned rays = 0;
   bool need = active;
   for (uint32_t kb = 0; kb < S.n_lights; kb += LB) {
     if (!__any(need)) break;  // nobody in the wavefront still needs a light
@@ -283,8 +289,9 @@ __device__ __forceinline__ bool shadow_by_sweeps(const DevScene& S, bool active,
     V3 pc = {p.x - S.center[0], p.y - S.center[1], p.z - S.center[2]};
     float thr = exotic ? -3.0e38f : filter_threshold(S, pc, rho_max);
     bool live = need && !(occl & 1u);
-    auto exact = [&](uint32_t slot, uint32_t mask) {
+    auto exact = [&](uint32_t slot, uint32_t mask) -> unsigned {
       const RTK_RO SphRecord& rec = S.sph_record[slot];
+      unsigned ran = 0;
       for (uint32_t r = 0; r < nb; ++r) {
         if (!((mask >> r) & 1u) || ((occl >> r) & 1u)) continue;
         const RTK_RO DevLight& L = S.lights[kb + r];
@@ -295,24 +302,26 @@ __device__ __forceinline__ bool shadow_by_sweeps(const DevScene& S, bool active,
         V3 d = divide_by_length(lv, lw, m, dw);
         double t0, t1;
         int n = intersect_sphere_record(S, rec, p, d, dw, t0, t1);
-        ++n_exact;
+        ++ran;
         if (n == 2 && ((t0 > 0.0 && t0 < m) || (t1 > 0.0 && t1 < m))) occl |= 1u << r;
       }
+      return ran;
     };
     auto done = [&]() { return (occl & 1u) != 0; };
-    sweep_filter<LB, WIDE>(S, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done);
+    sweep_filter<LB, WIDE>(S, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, wc, exact, done);
+    // the lights of the batch a point traces: up to and including the first blocked one
+    unsigned traced = 0;
     if (need) {
       occl &= (1u << nb) - 1u;
+      traced = nb;
       if (occl) {
-        rays += (unsigned)__builtin_ctz(occl) + 1u;
+        traced = (unsigned)__builtin_ctz(occl) + 1u;
         in_shadow = true;
         need = false;
-      } else {
-        rays += nb;
       }
     }
+    wc.shadow += lanes_total<bits_for(LB)>(traced);
   }
-  n_rays += rays;
   return in_shadow;
 }
 
@@ -322,7 +331,7 @@ __device__ __forceinline__ bool shadow_by_sweeps(const DevScene& S, bool active,
 // where the cluster sweep of 64 unrelated points costs thousands.  Lanes whose point lies below a
 // grid's floor (far-away points of a plane) take the cluster sweeps.
 template <int LB, bool WIDE>
-__device__ __forceinline__ bool shadow_by_grids(const DevScene& S, bool active, V3 p, unsigned& n_rays, unsigned& n_exact) {
+__device__ __forceinline__ bool shadow_by_grids(const DevScene& S, bool active, V3 p, WaveCount& wc) {
   const V3 pc = {p.x - S.center[0], p.y - S.center[1], p.z - S.center[2]};
   const float px = (float)pc.x, py = (float)pc.y, pz = (float)pc.z;
   bool in_range = active;
@@ -334,12 +343,10 @@ __device__ __forceinline__ bool shadow_by_grids(const DevScene& S, bool active, 
     rho_max = fmaxf(rho_max, fabsf(lf.w) * 1.0001f);
   }
   bool in_shadow = false;
-  unsigned rays = 0;
   const bool swept = active && !in_range;
   if (__any(swept)) {
-    unsigned swept_rays = 0;
-    const bool s = shadow_by_sweeps<LB, WIDE>(S, swept, p, swept_rays, n_exact);
-    if (swept) in_shadow = s, rays = swept_rays;
+    const bool s = shadow_by_sweeps<LB, WIDE>(S, swept, p, wc);
+    if (swept) in_shadow = s;
   }
   const float thr = filter_threshold(S, pc, rho_max);
   bool need = in_range;
@@ -353,8 +360,8 @@ __device__ __forceinline__ bool shadow_by_grids(const DevScene& S, bool active, 
     const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
     double dw;
     const V3 d = divide_by_length(lv, lw, m, dw);
+    wc.shadow += lanes_where(need);
     if (need) {
-      ++rays;
       for (uint32_t ip = 0; ip < S.n_planes; ++ip) {  // planes: exact
         const RTK_RO DevObject& ob = S.objects[S.plane_object[ip]];
         if (!plane_may_block(plane_side(ob, p), S.plane_light[ip * S.n_lights + k])) continue;
@@ -391,27 +398,26 @@ __device__ __forceinline__ bool shadow_by_grids(const DevScene& S, bool active, 
         }
       }
       while (__any(kept != 0ull)) {
+        wc.exact += lanes_where(kept != 0ull);
         if (kept != 0ull) {
           const uint32_t e = (uint32_t)__builtin_ctzll(kept);
           kept &= kept - 1ull;
           const RTK_RO SphRecord& rec = S.sph_record[S.grid_entries[first + base + e]];
           double t0, t1;
           const int n = intersect_sphere_record(S, rec, p, d, dw, t0, t1);
-          ++n_exact;
           if (n == 2 && ((t0 > 0.0 && t0 < m) || (t1 > 0.0 && t1 < m))) blocked = true, kept = 0ull, count = 0u;
         }
       }
     }
     if (need && blocked) in_shadow = true, need = false;
   }
-  n_rays += rays;
   return in_shadow;
 }
 
 template <int LB, bool WIDE>
-__device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3 p, unsigned& n_rays, unsigned& n_exact) {
-  if (WIDE && S.shadow_grid) return shadow_by_grids<LB, WIDE>(S, active, p, n_rays, n_exact);
-  return shadow_by_sweeps<LB, WIDE>(S, active, p, n_rays, n_exact);
+__device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3 p, WaveCount& wc) {
+  if (WIDE && S.shadow_grid) return shadow_by_grids<LB, WIDE>(S, active, p, wc);
+  return shadow_by_sweeps<LB, WIDE>(S, active, p, wc);
 }
 
 // ------------------------------------------------------------------------------------
@@ -420,7 +426,7 @@ __device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3
 // TRACK: the scene holds different refractive indices, so the entry before the winner (n1) matters.
 template <bool WIDE, bool TRACK>
 __device__ __forceinline__ void closest_general(const DevScene& S, bool active, V3 o, V3 d, Closest& best,
-                                                unsigned& n_exact, bool& graze) {
+                                                WaveCount& wc, bool& graze) {
   closest_init(best);
   constexpr bool track = TRACK;
   if (active) {
@@ -434,28 +440,28 @@ __device__ __forceinline__ void closest_general(const DevScene& S, bool active, 
   make_filter_ray(d, 0.0, gx[0], gy[0], gz[0], rho[0]);
   V3 pc = {o.x - S.center[0], o.y - S.center[1], o.z - S.center[2]};
   float thr = filter_threshold(S, pc, 0.0f);
-  auto exact = [&](uint32_t slot, uint32_t) {
+  auto exact = [&](uint32_t slot, uint32_t) -> unsigned {
     const RTK_RO SphRecord& rec = S.sph_record[slot];
     const uint32_t obj = rec.object;
     double t0, t1;
-    ++n_exact;
     if (intersect_sphere_record(S, rec, o, d, 0.0, t0, t1)) {
       closest_consider(best, t0, obj, track);
       closest_consider(best, t1, obj, track);
       if (track && fabs(t0 - t1) < 0.00001) graze = true;  // `Hit::eq` would call the two roots one hit
     }
+    return 1u;
   };
   auto done = [&]() { return false; };
   bool live = active;
   // hits behind the origin only matter for the refractive index n1 (the entry before the winner)
-  sweep_filter<1, WIDE>(S, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, exact, done, !track);
+  sweep_filter<1, WIDE>(S, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, wc, exact, done, !track);
 }
 
 // Closest hit of a camera ray (unit direction, shared origin).
 template <bool TRACK>
 __device__ __forceinline__ void closest_primary(const DevScene& S, const float4* __restrict__ prim,
                                                 const float4* __restrict__ prim_cluster, bool active, V3 o, V3 d,
-                                                Closest& best, unsigned& n_exact, bool& graze) {
+                                                Closest& best, WaveCount& wc, bool& graze) {
   closest_init(best);
   constexpr bool track = TRACK;
   if (active) {
@@ -467,14 +473,13 @@ __device__ __forceinline__ void closest_primary(const DevScene& S, const float4*
   }
   auto exact = [&](uint32_t obj) {
     double t0, t1;
-    ++n_exact;
     if (intersect_object(S.objects[obj], o, d, 0.0, t0, t1)) {
       closest_consider(best, t0, obj, track);
       closest_consider(best, t1, obj, track);
       if (track && fabs(t0 - t1) < 0.00001) graze = true;
     }
   };
-  sweep_primary(S, prim, prim_cluster, active, (float)d.x, (float)d.y, (float)d.z, exact);
+  sweep_primary(S, prim, prim_cluster, active, (float)d.x, (float)d.y, (float)d.z, wc, exact);
 }
 
 }  // namespace rtk

@@ -99,23 +99,30 @@ __device__ __forceinline__ double literal_n1(const DevScene& S, V3 o, V3 d, uint
   return last_obj == 0xffffffffu ? 1.0 : S.objects[last_obj].refractivity;
 }
 // `Scene::is_shadowed` (src/scene.rs:208-225): one shadow ray per light until one is blocked.
-__device__ __forceinline__ bool shadow_brute(const DevScene& S, bool active, V3 p, unsigned& n_rays) {
-  if (!active) return false;
+__device__ __forceinline__ bool shadow_brute(const DevScene& S, bool active, V3 p, WaveCount& wc) {
+  bool need = active, in_shadow = false;
   for (uint32_t k = 0; k < S.n_lights; ++k) {
-    ++n_rays;
-    const RTK_RO DevLight& L = S.lights[k];
-    const V3 lv = ld3(L.pos) - p;
-    const double lw = L.pos[3] - 1.0;
-    const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
-    double dw;
-    const V3 d = divide_by_length(lv, lw, m, dw);
-    for (uint32_t obj = 0; obj < S.n_objects; ++obj) {
-      double t0, t1;
-      const int n = intersect_object(S.objects[obj], p, d, dw, t0, t1);
-      if ((n >= 1 && t0 > 0.0 && t0 < m) || (n == 2 && t1 > 0.0 && t1 < m)) return true;
+    const unsigned n_need = lanes_where(need);
+    if (n_need == 0u) break;
+    wc.shadow += n_need;
+    if (need) {
+      const RTK_RO DevLight& L = S.lights[k];
+      const V3 lv = ld3(L.pos) - p;
+      const double lw = L.pos[3] - 1.0;
+      const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+      double dw;
+      const V3 d = divide_by_length(lv, lw, m, dw);
+      for (uint32_t obj = 0; obj < S.n_objects; ++obj) {
+        double t0, t1;
+        const int n = intersect_object(S.objects[obj], p, d, dw, t0, t1);
+        if ((n >= 1 && t0 > 0.0 && t0 < m) || (n == 2 && t1 > 0.0 && t1 < m)) {
+          in_shadow = true, need = false;
+          break;
+        }
+      }
     }
   }
-  return false;
+  return in_shadow;
 }
 
 // The children of a hit: `reflected_color` and `refracted_color` (src/scene.rs:228-272) with the
@@ -166,23 +173,21 @@ __device__ __forceinline__ void emit_children(const DevScene& S, const RTK_RO De
 template <bool SECONDARY, bool PRIMARY_FILTER, int LB, bool WIDE, bool BRUTE, bool TRACK, typename Sink>
 __device__ __forceinline__ void trace_step(const DevScene& S, const float4* __restrict__ prim,
                                            const float4* __restrict__ prim_cluster, bool have, bool camera_sweep, V3 ro, V3 rd,
-                                           double weight, int depth, Sink& sink, unsigned& c_primary,
-                                           unsigned& c_shadow, unsigned& c_secondary, unsigned& c_exact) {
+                                           double weight, int depth, Sink& sink, WaveCount& wc) {
   const V3 scene_ambient = ld3(S.ambient);
-  if (have) {
-    if (depth == 0)
-      ++c_primary;
-    else
-      ++c_secondary;
+  {
+    const unsigned n_camera = lanes_where(have && depth == 0);
+    wc.primary += n_camera;
+    wc.secondary += lanes_where(have) - n_camera;
   }
   Closest best;
   bool graze = false;  // some sphere has both roots within 1e-5 of each other on this ray
   if (BRUTE)
     closest_brute<TRACK>(S, have, ro, rd, best, graze);
   else if (PRIMARY_FILTER && camera_sweep)
-    closest_primary<TRACK>(S, prim, prim_cluster, have, ro, rd, best, c_exact, graze);
+    closest_primary<TRACK>(S, prim, prim_cluster, have, ro, rd, best, wc, graze);
   else
-    closest_general<WIDE, TRACK>(S, have, ro, rd, best, c_exact, graze);
+    closest_general<WIDE, TRACK>(S, have, ro, rd, best, wc, graze);
 
   const bool hit = have && best.obj != 0xffffffffu;
   if (have && !hit) sink.term(scene_ambient, weight);  // trace_inner: miss -> ambient_color
@@ -215,7 +220,7 @@ __device__ __forceinline__ void trace_step(const DevScene& S, const float4* __re
     }
   }
 
-  const bool in_shadow = BRUTE ? shadow_brute(S, hit, over, c_shadow) : shadow_sweeps<LB, WIDE>(S, hit, over, c_shadow, c_exact);
+  const bool in_shadow = BRUTE ? shadow_brute(S, hit, over, wc) : shadow_sweeps<LB, WIDE>(S, hit, over, wc);
 
   if (hit) {
     const RTK_RO DevObject& ob = S.objects[obj];
@@ -231,8 +236,7 @@ __device__ __forceinline__ void trace_step(const DevScene& S, const float4* __re
 template <bool SECONDARY, bool PRIMARY_FILTER, int LB, bool WIDE, bool BRUTE, bool TRACK>
 __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restrict__ prim,
                                         const float4* __restrict__ prim_cluster, bool valid, V3 o,
-                                        V3 d, unsigned& c_primary, unsigned& c_shadow, unsigned& c_secondary,
-                                        unsigned& c_exact) {
+                                        V3 d, WaveCount& wc) {
   V3 color = {0, 0, 0};
   StackEntry stack[SECONDARY ? kMaxDepth + 1 : 1];
   int sp = 0;
@@ -261,8 +265,7 @@ __device__ __forceinline__ V3 trace_ray(const DevScene& S, const float4* __restr
     } else if (iter > 0) {
       break;
     }
-    trace_step<SECONDARY, PRIMARY_FILTER, LB, WIDE, BRUTE, TRACK>(S, prim, prim_cluster, have, iter == 0, ro, rd, weight, depth, sink,
-                                                                  c_primary, c_shadow, c_secondary, c_exact);
+    trace_step<SECONDARY, PRIMARY_FILTER, LB, WIDE, BRUTE, TRACK>(S, prim, prim_cluster, have, iter == 0, ro, rd, weight, depth, sink, wc);
   }
   return color;
 }

@@ -32,20 +32,6 @@ namespace rtk {
 #define RTK_WF_OCC 4
 #endif
 
-__device__ __forceinline__ void add_counters(DevCounters* counters, unsigned c_primary, unsigned c_shadow, unsigned c_secondary,
-                                             unsigned c_exact) {
-  c_primary = wave_sum(c_primary);
-  c_shadow = wave_sum(c_shadow);
-  c_secondary = wave_sum(c_secondary);
-  c_exact = wave_sum(c_exact);
-  if ((threadIdx.x & 63u) == 0) {
-    if (c_primary) atomicAdd(&counter_shard(counters)->rays_primary, (unsigned long long)c_primary);
-    if (c_shadow) atomicAdd(&counter_shard(counters)->rays_shadow, (unsigned long long)c_shadow);
-    if (c_secondary) atomicAdd(&counter_shard(counters)->rays_secondary, (unsigned long long)c_secondary);
-    if (c_exact) atomicAdd(&counter_shard(counters)->exact_tests, (unsigned long long)c_exact);
-  }
-}
-
 // Start of a pass or of a level: [kCtrlLevelEnd + level] = nodes so far (at most the capacity).
 // set_nodes != 0 (start of a pass): the camera rays of the pass are nodes 0 .. set_nodes - 1.
 __global__ void wf_mark_kernel(unsigned int* ctrl, uint32_t level, uint32_t cap_nodes, uint32_t set_nodes) {
@@ -70,15 +56,14 @@ __global__ void __launch_bounds__(kBlock, 4) wf_primary_kernel(DevScene S, DevCa
   const bool valid = x < C.width && y < C.height;
   const V3 origin = ld3(C.origin);
   const V3 dir = camera_ray_direction(C, x, y);
-  unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
+  WaveCount wc;
   __shared__ ParkedChild s_park[2 * kBlock];
   __shared__ uint32_t s_counts[10];
   ParkSink sink(s_park);
-  trace_step<true, true, LB, WIDE, false, TRACK>(S, prim, prim_cluster, valid, true, origin, dir, 1.0, 0, sink, c_primary, c_shadow,
-                                                 c_secondary, c_exact);
+  trace_step<true, true, LB, WIDE, false, TRACK>(S, prim, prim_cluster, valid, true, origin, dir, 1.0, 0, sink, wc);
   sink.flush(B, gridDim.x * kBlock, 1u, s_counts);
   sink.store(B.outs[blockIdx.x * kBlock + threadIdx.x]);
-  add_counters(B.counters, c_primary, c_shadow, c_secondary, c_exact);
+  flush_counts(counter_shard(B.counters), wc);
 }
 
 // Level l >= 1: the nodes queued by level l - 1 (all of depth l), one lane per node, 256 consecutive
@@ -87,7 +72,7 @@ __global__ void __launch_bounds__(kBlock, 4) wf_primary_kernel(DevScene S, DevCa
 template <int LB, bool WIDE, bool TRACK>
 __global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_level_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
   const uint32_t end = B.ctrl[kCtrlLevelEnd + level];
-  unsigned c_primary = 0, c_shadow = 0, c_secondary = 0, c_exact = 0;
+  WaveCount wc;
   __shared__ ParkedChild s_park[2 * kBlock];
   __shared__ uint32_t s_counts[10];
   __shared__ uint32_t s_base;
@@ -110,12 +95,11 @@ __global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_level_kernel(DevScene S
     }
     ParkSink sink(s_park);
     if (__any(have))
-      trace_step<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, weight, (int)level, sink, c_primary,
-                                                      c_shadow, c_secondary, c_exact);
+      trace_step<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, weight, (int)level, sink, wc);
     sink.flush(B, n_roots, level + 1u, s_counts);  // its barriers also keep s_base until every thread has read it
     if (have) sink.store(B.outs[i]);
   }
-  add_counters(B.counters, c_primary, c_shadow, c_secondary, c_exact);
+  flush_counts(counter_shard(B.counters), wc);
 }
 
 // The pixels of the pass's tiles from the node records: depth-first walk, terms added in the order

@@ -104,8 +104,8 @@ def cpu_baseline(rtk, scene, camera):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed frames (default 200)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed frames before them (default 10)")
     ap.add_argument("--workload", default="C4", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -114,7 +114,16 @@ def main():
     ap.add_argument("--loopback", action="store_true",
                     help="single process, --gpus N on ONE device: N members on device 0 exchanging through RCCL's send-to-self "
                          "(a functional rehearsal of the multi-GPU frame, not a scaling measurement)")
+    ap.add_argument("--partition", default="rows", choices=["rows", "bands"],
+                    help="single process, N > 1: one run of rows per member with boundaries laid by measurement before the "
+                         "warm-up (default), or bands of tile rows dealt in rounds")
+    ap.add_argument("--root-share", type=int, default=1, help="--partition bands: bands the first member holds in every round")
+    ap.add_argument("--allow-peer", action="store_true",
+                    help="single process, N > 1: accept peer-to-peer copies where RCCL did not come up (otherwise the run fails: "
+                         "the rows are meant to reach member 0 through RCCL)")
     args = ap.parse_args()
+    steps = 200 if args.steps is None else args.steps
+    warmup = 10 if args.warmup is None else args.warmup
 
     # ONE JSON line on stdout: libraries that print to the C-level stdout (RCCL announces its version
     # there when a communicator comes up) are sent to stderr; the line itself goes to the saved descriptor
@@ -163,75 +172,129 @@ def main():
         if world > 1:
             tdist.barrier()
 
+    def timed(run):
+        """W untimed frames, then exactly K timed ones between barriers; the slowest rank's time."""
+        run(warmup)
+        sync_all()
+        t0 = time.perf_counter()
+        run(steps)  # every frame is complete on rank 0 / member 0 when the streams have drained
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     dev = device.Device(local_rank)
     handle = dev.upload(scene)  # the scene is resident in HBM before anything is timed
     root_share = 1
     partition = "whole frame on one GPU"
+    multi = None  # what a run over several GPUs adds to the line
     if in_process_group:
         group_mod = importlib.import_module("raytracer-rust_amd.group")
         ids = [0] * args.gpus if args.loopback else list(range(args.gpus))
         grp = group_mod.DeviceGroup(ids)
+        if grp.exchange() != "rccl" and not args.allow_peer:
+            grp.close()
+            sys.exit(f"bench.py --gpus {args.gpus}: the members' rows would travel as {grp.exchange()!r}, not through RCCL "
+                     "(librccl did not load or its communicators did not come up); pass --allow-peer to measure that instead")
         grp.upload(scene)
         outs = [(torch.empty((camera.height, camera.width, 3), dtype=torch.float32, device=grp.tdev),
                  torch.empty((camera.height, camera.width, 4), dtype=torch.uint8, device=grp.tdev)) for _ in range(2)]
-        partition = (f"bands of {grp.band_tile_rows(camera.height)} tile rows (8 px each) dealt round-robin to {args.gpus} members of "
-                     "one process; FP32 RGB + RGBA8 rows land in place on member 0 (exchange: " + grp.exchange() + ")"
-                     + (" (loopback: all members on device 0)" if args.loopback else ""))
 
-        def run(n):  # two frames in flight: output buffers and the members' band buffers alternate
+        def lay(want_rgb):  # the partition of a leg: boundaries by measurement for exactly its outputs, or bands
+            if args.partition == "rows":
+                grp.balance(camera, want_rgb=want_rgb, want_rgba8=True)
+            else:
+                grp.set_rows(camera.height, None)
+                grp.set_root_share(args.root_share)
+
+        def run_both(n):  # two frames in flight: output buffers and the members' band buffers alternate
             for k in range(n):
                 grp.render_device(camera, out_rgb=outs[k % 2][0], out_rgba8=outs[k % 2][1])
-    else:
-        renderer = rdist.gpu_renderer(dev, handle, camera, group=None)
-        # More than one GPU: rank 0 receives all tiles and sends none, so it can take a larger share of
-        # the frame.  The share is timed on this machine before the warm-up (RTK_ROOT_SHARE fixes it).
-        if world > 1:
-            try:
-                if os.environ.get("RTK_ROOT_SHARE"):
-                    renderer.set_root_share(int(os.environ["RTK_ROOT_SHARE"]))
-                else:
-                    renderer.autotune(frames=12, sync=torch.cuda.synchronize)
-            except Exception as exc:  # the same failure on every rank: fall back to the plain round-robin
-                print(f"rank {rank}: partition tuning failed ({exc}); using equal shares", file=sys.stderr, flush=True)
-                renderer.in_flight.clear()
-                renderer.set_root_share(1)
-            root_share = renderer.root_share
-            partition = ("32x8 px tiles dealt round-robin to ranks (one process per GPU); FP32 RGB + RGBA8 gathered to rank 0"
-                         f"; rank 0 renders {root_share} of every {world - 1 + root_share} tiles")
 
-        def run(n):  # with more than one GPU two frames are in flight: the gather of one overlaps the render of the next
-            for _ in renderer.stream(n):
-                pass
+        def run_px(n):
+            for k in range(n):
+                grp.render_device(camera, want_rgb=False, out_rgba8=outs[k % 2][1])
 
-    # Steps are queued back to back; nothing waits on a frame inside the timed region.  The library keeps
-    # HIP-event times of its last 64 launches (events on the launch stream), read after the region; the
-    # ray counters are those of the last frame (every frame of a fixed scene traces the same rays).
-    run(args.warmup)
-    sync_all()
-    t0 = time.perf_counter()
-    run(args.steps)  # every frame is complete on rank 0 / member 0 when the streams have drained
-    sync_all()
-    elapsed = time.perf_counter() - t0
-
-    gather_ms = None
-    if in_process_group:
+        # the 8-bit frame alone first (what the reference finally writes: 4 bytes per pixel travel), then the
+        # headline leg with both outputs, so that the counters read afterwards are the headline's
+        lay(False)
+        elapsed_px = timed(run_px)
+        info_px = grp.info()
+        lay(True)
+        elapsed = timed(run_both)
+        info = grp.info()
         gst = grp.stats()
         kernel_ms, rays_ms = [gst.kernel_ms], [gst.rays_ms]  # the slowest member's launch of the last frame
-        local_rays = frame_rays = float(gst.rays)
-        gather_ms = gst.gather_ms
+        frame_rays = float(gst.rays)
+        slowest = max(range(len(info["share_ms"])), key=lambda r: info["share_ms"][r])
+        local_rays = float(info["share_rays"][slowest])  # rays of the launch whose time is quoted
+        partition = ((f"one run of tile rows per member, boundaries laid by measurement ({info['share_tile_rows']} tile rows)"
+                      if info["partition"] == "rows" else
+                      f"bands of {grp.band_tile_rows(camera.height)} tile rows (8 px each) dealt in rounds to {args.gpus} members, "
+                      f"member 0 holding {info['root_share']} per round")
+                     + "; one process; FP32 RGB + RGBA8 rows land in place on member 0 (exchange: " + info["exchange"] + ")"
+                     + (" (loopback: all members on device 0)" if args.loopback else ""))
+        multi = {
+            "exchange": info["exchange"],
+            "messages_per_frame": info["messages"], "bytes_into_root_per_frame": info["bytes_into_root"],
+            "gather_ms_last_frame": info["gather_ms"], "share_ms": info["share_ms"], "share_tile_rows": info["share_tile_rows"],
+            "rgba8_only": {"messages_per_frame": info_px["messages"], "bytes_into_root_per_frame": info_px["bytes_into_root"],
+                           "gather_ms_last_frame": info_px["gather_ms"], "share_ms": info_px["share_ms"],
+                           "share_tile_rows": info_px["share_tile_rows"], "ms_per_step": elapsed_px / steps * 1e3},
+        }
     else:
-        kernel_ms, rays_ms = dev.timing_history(args.steps)
-        local_rays = dev.stats().rays  # of this rank's last launch (with a larger share rank 0 launches several per frame)
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        def renderer_for(want_rgb):
+            r = rdist.gpu_renderer(dev, handle, camera, group=None, want_rgb=want_rgb)
+            # More than one GPU: rank 0 receives all tiles and sends none, so it can take a larger share of
+            # the frame.  The share is timed on this machine before the warm-up (RTK_ROOT_SHARE fixes it).
+            if world > 1:
+                try:
+                    if os.environ.get("RTK_ROOT_SHARE"):
+                        r.set_root_share(int(os.environ["RTK_ROOT_SHARE"]))
+                    else:
+                        r.autotune(frames=12, sync=torch.cuda.synchronize)
+                except Exception as exc:  # the same failure on every rank: fall back to the plain round-robin
+                    print(f"rank {rank}: partition tuning failed ({exc}); using equal shares", file=sys.stderr, flush=True)
+                    r.in_flight.clear()
+                    r.set_root_share(1)
+            return r
+
+        def runner(r):
+            def run(n):  # with more than one GPU two frames are in flight: the gather of one overlaps the render of the next
+                for _ in r.stream(n):
+                    pass
+            return run
+
+        elapsed_px = None
         if world > 1:
-            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            renderer_px = renderer_for(False)
+            elapsed_px = timed(runner(renderer_px))
+            px_share = renderer_px.root_share
+        renderer = renderer_for(True)
+        elapsed = timed(runner(renderer))
+        root_share = renderer.root_share
+        kernel_ms, rays_ms = dev.timing_history(steps)
+        local_rays = dev.stats().rays  # of this rank's last launch (with a larger share rank 0 launches several per frame)
         # rays of one frame: counted once, outside the timed region, by a whole-frame launch (every
         # frame of a fixed scene traces the same rays, however its tiles are dealt)
         frame_rays = float(local_rays)
         if world > 1:
             dev.render_device(handle, camera, want_rgb=False)
             frame_rays = float(dev.stats().rays)
+            partition = ("32x8 px tiles dealt round-robin to ranks (one process per GPU); FP32 RGB + RGBA8 gathered to rank 0 "
+                         f"through the process group (RCCL); rank 0 renders {root_share} of every {world - 1 + root_share} tiles")
+            tiles = -(-camera.width // 32) * -(-camera.height // 8)
+            multi = {
+                "exchange": "rccl (torch.distributed, backend nccl)",
+                "messages_per_frame": world - 1 if root_share > 1 else 1,
+                "bytes_into_root_per_frame": int(tiles * 256 * 16 * (world - 1) / (world - 1 + root_share)),
+                "root_share": root_share,
+                "rgba8_only": {"root_share": px_share, "ms_per_step": elapsed_px / steps * 1e3,
+                               "bytes_into_root_per_frame": int(tiles * 256 * 4 * (world - 1) / (world - 1 + px_share))},
+            }
 
     if rank == 0:
         avg_kernel_ms = sum(kernel_ms) / max(1, len(kernel_ms))
@@ -239,9 +302,10 @@ def main():
         seconds = avg_rays_ms * 1e-3
         # The reference answers every ray with a sweep over all N objects (26 flops per ray-sphere test, 8
         # per ray-plane test).  The kernel delivers the outcome of that sweep while opening 3-5 of 157
-        # clusters per wavefront, so "reference sweep / kernel time" says how much work the hierarchy
-        # avoids -- it is far above the chip's peak and is NOT a utilisation figure.
-        sweep_tflops = local_rays * fpr / seconds / 1e12 if seconds > 0 else 0.0
+        # clusters per wavefront, so "reference sweep / time" says how much work the hierarchy avoids --
+        # it is far above the chip's peak and is NOT a utilisation figure.  Whole job: all rays of a
+        # frame over the frame time, per GPU.
+        sweep_tflops = frame_rays * fpr / (elapsed / steps) / 1e12 if elapsed > 0 else 0.0
         # Utilisation: flops the dominant kernel really executes per launch (rocprofv3 PMC instruction
         # mix x active lanes, taken from this very tree: profiles/measured_counters.json carries a hash
         # of the kernel sources) over the launch time measured live with HIP events in this run.
@@ -251,12 +315,12 @@ def main():
         exec_f32 = f32_flops / seconds / 1e12 if f32_flops and seconds > 0 else None
         out = {
             "metric": "Mrays/sec at 3840x2160 (1/2/4/8 MI355X) + % of FP32 VALU peak",
-            "value": frame_rays * args.steps / elapsed / 1e6,
+            "value": frame_rays * steps / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": n_gpus,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -266,6 +330,7 @@ def main():
                 "workload": f"{args.workload}: {n_sph} spheres + {n_pl} plane(s), {len(scene.lights)} lights, "
                             f"{camera.width}x{camera.height}, 1 spp, opaque materials",
                 "rays_per_frame": int(frame_rays),
+                "outputs": "FP32 RGB (12 B/px) + RGBA8 (4 B/px) frames in the HBM of GPU 0",
                 "tiles": partition,
                 "processes": 1 if world == 1 else world,
                 "precision": "every decision and colour in f64 (the reference's formulas); FP32 only in the conservative culling tests; FP32 RGB + RGBA8 store",
@@ -290,53 +355,31 @@ def main():
                 "profiled_valu_busy": measured.get("valu_busy"),
                 "profiled_valu_lane_util": measured.get("valu_lane_util"),
                 "profiled_wave_cycles_waiting": measured.get("wait_any_share"),
+                "profiled_salu_per_wavefront": measured.get("salu_per_wavefront"),
+                "profiled_valu_per_wavefront": measured.get("valu_per_wavefront"),
                 "rays_per_launch": int(local_rays),
-                "framebuffer_store_GBps": (camera.width * camera.height * 16 / (n_gpus - 1 + root_share)) / (avg_kernel_ms * 1e-3) / 1e9
-                if avg_kernel_ms > 0 else None,  # sanity counter: 12 B FP32 RGB + 4 B RGBA8 per pixel, written once
+                "framebuffer_store_GBps": (local_rays / frame_rays * camera.width * camera.height * 16) / (avg_kernel_ms * 1e-3) / 1e9
+                if avg_kernel_ms > 0 and frame_rays > 0 else None,  # sanity counter: 12 B FP32 RGB + 4 B RGBA8 per pixel, written once (the launch's share of the frame taken by its rays)
                 "note": "achieved = f64 flops the kernel executes per launch (PMC instruction mix x 64 lanes x share of lanes "
                         "active; fma = 2) / HIP-event time of that kernel in this run; peak = vector f64 peak (256 CUs x 2.4 GHz x "
-                        "128 flop/clk/CU). The kernel is bound by instruction issue (VALU busy ~2/3 of cycles by the instruction mix, a third of the instructions moves, selects and "
-                        "compares) and dependent-load latency at 5 waves per SIMD, not by f64 arithmetic",
+                        "128 flop/clk/CU). The kernel is bound by instruction issue and dependent-load latency at 5 waves per SIMD, "
+                        "not by f64 arithmetic",
             },
             "reference_sweep_equivalent": {
                 "flops_per_ray": fpr,
                 "TFLOPs": sweep_tflops,
-                "x_fp32_valu_peak": sweep_tflops / PEAK_FP32_TFLOPS,
+                "x_fp32_valu_peak_per_gpu": sweep_tflops / max(1, n_gpus) / PEAK_FP32_TFLOPS,
                 "note": "what the reference's brute-force sweep (every ray against every object) would need to execute per "
-                        "second to deliver these rays; the kernel culls nearly all of it, so this is a speed-up factor over "
+                        "second to deliver this job's rays; the kernel culls nearly all of it, so this is a speed-up factor over "
                         "the sweep run at peak, not a fraction of peak",
             },
         }
-        if gather_ms is not None:
-            out["roofline"]["gather_ms_last_frame"] = gather_ms
+        if multi is not None:
+            out["multi_gpu"] = multi
+            out["value_rgba8_only"] = frame_rays * steps / elapsed_px / 1e6
         if n_gpus == 1 and not args.no_extra:
-            extra = {}
-            for name in ("C1", "C2", "C3", "C3_glass_1080p", "C4_glass_1080p"):
-                if name == args.workload:
-                    continue
-                if name == "C1":  # the reference's bundled scene at its own resolution (src/main.rs:17-20)
-                    s2 = rtk.PackedScene.from_yaml_file(os.path.join(ROOT, "tests", "golden", "test01.yaml")).build()
-                    c2 = rtk.Camera(1920, 1080, rtk.PI / 3.0)
-                elif name.endswith("_glass_1080p"):  # a quarter of the spheres glass, reflective floor: secondary rays
-                    n2 = 1000 if name.startswith("C3") else 10000
-                    s2 = rtk.synthetic.make_scene(n2, True, 4, 0xC0FFEE00 + n2, glass=True)
-                    c2 = rtk.synthetic.make_camera(n2, 1920, 1080)
-                else:
-                    s2, c2 = rtk.synthetic.config(name)
-                h2 = dev.upload(s2)
-                f2, _, _ = flops_per_ray(s2, rtk)
-                best = None
-                for _ in range(5):
-                    dev.render_device(h2, c2)
-                    st = dev.stats()
-                    best = st if best is None or st.kernel_ms < best.kernel_ms else best
-                extra[name] = {
-                    "frame": f"{c2.width}x{c2.height}", "rays": int(best.rays), "kernel_ms": best.kernel_ms,
-                    "Mrays_per_s": best.rays / best.kernel_ms / 1e3,
-                    "reference_sweep_x_fp32_valu_peak": best.rays * f2 / (best.kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                }
-                h2.release()
-            out["other_configs_kernel_only"] = extra
+            out["other_configs_kernel_only"] = other_configs(rtk, dev, args.workload)
+            out["host_buffer_call"] = host_buffer_call(rtk, dev, scene, camera)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rtk, scene, camera)
         sys.stdout.flush()
@@ -347,6 +390,66 @@ def main():
     if world > 1:
         tdist.barrier()
         tdist.destroy_process_group()
+
+
+def other_configs(rtk, dev, headline):
+    """Kernel-only times of the other BASELINE configurations (and two glass scenes), scene resident, best of 5."""
+    extra = {}
+    for name in ("C1", "C2", "C3", "C4", "C5", "C3_glass_1080p", "C4_glass_1080p"):
+        if name == headline:
+            continue
+        if name == "C1":  # the reference's bundled scene at its own resolution (src/main.rs:17-20)
+            s2 = rtk.PackedScene.from_yaml_file(os.path.join(ROOT, "tests", "golden", "test01.yaml")).build()
+            c2 = rtk.Camera(1920, 1080, rtk.PI / 3.0)
+        elif name.endswith("_glass_1080p"):  # a quarter of the spheres glass, reflective floor: secondary rays
+            n2 = 1000 if name.startswith("C3") else 10000
+            s2 = rtk.synthetic.make_scene(n2, True, 4, 0xC0FFEE00 + n2, glass=True)
+            c2 = rtk.synthetic.make_camera(n2, 1920, 1080)
+        else:
+            s2, c2 = rtk.synthetic.config(name)  # C5: the whole 16384 x 16384 frame (4.3 GB of FP32 RGB + RGBA8 in HBM)
+        h2 = dev.upload(s2)
+        f2, _, _ = flops_per_ray(s2, rtk)
+        best = None
+        out_rgb = out_px = None
+        for _ in range(5):
+            out_rgb, out_px = dev.render_device(h2, c2, out_rgb=out_rgb, out_rgba8=out_px)
+            st = dev.stats()
+            best = st if best is None or st.kernel_ms < best.kernel_ms else best
+        extra[name] = {
+            "frame": f"{c2.width}x{c2.height}", "rays": int(best.rays), "kernel_ms": best.kernel_ms,
+            "Mrays_per_s": best.rays / best.kernel_ms / 1e3,
+            "reference_sweep_x_fp32_valu_peak": best.rays * f2 / (best.kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+        }
+        h2.release()
+        del out_rgb, out_px
+    return extra
+
+
+def host_buffer_call(rtk, dev, scene, camera):
+    """`rtk_render` as the reference's `camera.render(&scene)` signature implies: scene and frame in HOST
+    memory, every call flattens (or recognises) the scene, renders, and copies both frames back.  PCIe
+    inclusive; never the headline value."""
+    import ctypes as C
+
+    import torch
+
+    device = importlib.import_module("raytracer-rust_amd.device")
+    lib = device.library()
+    s, cam = scene.to_abi(), camera.to_abi()
+    # page-locked destinations, allocated once as a host application would
+    rgb = torch.empty((cam.height, cam.width, 3), dtype=torch.float32, pin_memory=True)
+    px = torch.empty((cam.height, cam.width, 4), dtype=torch.uint8, pin_memory=True)
+    st = rtk.abi.rtk_stats()
+    calls = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        device._check(lib.rtk_render(dev.ctx, C.byref(s), C.byref(cam), C.c_void_p(rgb.data_ptr()), C.c_void_p(px.data_ptr()), C.byref(st)))
+        calls.append((time.perf_counter() - t0) * 1e3)
+    rays = st.rays
+    same = min(calls[1:])
+    return {"workload": f"{camera.width}x{camera.height}, page-locked host frames, FP32 RGB + RGBA8",
+            "first_call_ms": calls[0], "same_scene_call_ms": same, "Mrays_per_s": rays / same / 1e3,
+            "note": "first call: flatten + upload + render + copy back; later calls find the scene of the call before on the device"}
 
 
 if __name__ == "__main__":

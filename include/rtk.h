@@ -351,9 +351,12 @@ int rtk_get_timing_history(rtk_context* ctx, uint32_t capacity, double* kernel_m
  * multi-GPU frame.  librccl.so.1 is loaded when the first group is created; a group of one
  * member needs no exchange and does not load it.  If RCCL cannot be loaded or its communicators
  * do not come up, the same bands travel as peer-to-peer copies (hipMemcpyPeerAsync, one per
- * band, on the sending member's stream) into the same final rows.  The environment variable
- * RTK_GROUP_EXCHANGE, read by rtk_group_create, overrides the choice: "rccl" (RTK_ERR_RCCL
- * rather than a fall-back) or "peer" (copies from the start). */
+ * band, on the sending member's stream) into the same final rows; rtk_group_exchange() and
+ * rtk_group_info.exchange say which.  The environment variable RTK_GROUP_EXCHANGE, read by
+ * rtk_group_create, overrides the choice: "rccl" (RTK_ERR_RCCL rather than a fall-back) or "peer"
+ * (copies from the start).  A frame for which only d_rgba8 is given moves 4 bytes per pixel and
+ * allocates no FP32 band buffers.  Every rtk_group_* call leaves the calling thread's current HIP
+ * device as it found it. */
 typedef struct rtk_group rtk_group;
 int rtk_group_create(const int* device_ids, int n_members, rtk_group** out);
 void rtk_group_destroy(rtk_group* group);
@@ -376,15 +379,58 @@ int rtk_group_get_stats(rtk_group* group, rtk_stats* stats);
 /* Tile rows per band the group uses for a frame of `height` pixel rows. */
 uint32_t rtk_group_band_tile_rows(const rtk_group* group, uint32_t height);
 /* How many bands of a frame each member gets (about; a band is a whole number of tile rows):
- * more bands even out rows that cost differently, fewer mean fewer, larger messages to the root.
- * 0 restores the library's choice.  Takes effect from the next frame. */
+ * more bands even out rows that cost differently, fewer mean fewer, larger messages to the root
+ * (every band of every other member is one message per output).  0 restores the library's choice:
+ * 4 per member, 3 from 4 members on, 2 from 8 members on.  Takes effect from the next frame. */
 int rtk_group_set_bands_per_member(rtk_group* group, uint32_t bands_per_member);
+/* The root's rows do not travel, so on frames whose exchange takes longer than a member's share the
+ * root should render more than the others: with root_share = a the bands are dealt in rounds of
+ * n_members - 1 + a, and the root holds the first a of every round (one launch, its rows in place).
+ * 0 or 1: equal shares.  Takes effect from the next frame. */
+int rtk_group_set_root_share(rtk_group* group, uint32_t root_share);
+/* The other partition: ONE run of tile rows per member -- member r renders the tile rows
+ * [first_tile_row[r], first_tile_row[r + 1]) of frames of `height` pixel rows (n_members + 1
+ * boundaries from 0 to ceil(height / RTK_TILE_H), not decreasing; an empty run is allowed), so every
+ * other member's rows reach the root as one message per output.  Frames of another height, and all
+ * frames after a call with first_tile_row == NULL, are dealt in bands again. */
+int rtk_group_set_rows(rtk_group* group, uint32_t height, const uint32_t* first_tile_row);
+/* Lays such boundaries by measurement, for this scene, camera and set of outputs: every member
+ * renders a run of rows alone and is timed, and the boundaries are moved until the largest of a
+ * member's kernel time and -- for every member but the root -- the time its bytes take on one link is
+ * as small as the cost per row measured so far allows (`rounds` measurements; 0: 4).  link_gbps:
+ * the rate one member's rows reach the root at, in GB/s (0: the environment variable
+ * RTK_GROUP_LINK_GBPS, else 100).  Synchronises; leaves the boundaries set (rtk_group_set_rows). */
+int rtk_group_balance(rtk_group* group, const rtk_camera* camera, int with_rgb_f32, int with_rgba8, uint32_t rounds,
+                      double link_gbps);
+/* The last frame in numbers a scaling run can be read from.  Waits for the frame. */
+#define RTK_GROUP_INFO_MEMBERS 16
+typedef struct rtk_group_info {
+  uint32_t n_members;
+  uint32_t exchange;        /* 0 none (one member), 1 RCCL, 2 peer-to-peer copies */
+  uint32_t root_share;      /* as set */
+  uint32_t rows_mode;       /* 1: boundaries from rtk_group_set_rows / rtk_group_balance are set */
+  uint32_t messages;        /* sends (= receives) or copies of the last frame's exchange */
+  uint32_t reserved_;
+  uint64_t bytes_into_root; /* bytes the exchange moved into the caller's frame */
+  double gather_ms;         /* as rtk_stats.gather_ms */
+  /* per member, the first RTK_GROUP_INFO_MEMBERS of them: tile rows, kernel time and rays of its share */
+  uint32_t share_tile_rows[RTK_GROUP_INFO_MEMBERS];
+  double share_ms[RTK_GROUP_INFO_MEMBERS];
+  uint64_t share_rays[RTK_GROUP_INFO_MEMBERS];
+} rtk_group_info;
+int rtk_group_get_info(rtk_group* group, rtk_group_info* info);
 
 /* Thread-local description of the last failure on this thread ("" if none). */
 const char* rtk_last_error(void);
 
 /* Library version string and the code-object architecture it was built for. */
 const char* rtk_version(void);
+/* The number of this header's struct layouts and entry points: it changes whenever a struct of
+ * this header changes size or layout or an entry point changes meaning.  A host built against
+ * this header compares it with RTK_ABI_VERSION before passing structs.  (2: rtk_stats has
+ * gather_ms and RTK_ERR_RCCL exists; 3: rtk_group_info, shares and rows of a group.) */
+#define RTK_ABI_VERSION 3
+uint32_t rtk_abi_version(void);
 
 #ifdef __cplusplus
 }

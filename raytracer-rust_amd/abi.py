@@ -128,6 +128,26 @@ class rtk_banding(C.Structure):
     ]
 
 
+RTK_GROUP_INFO_MEMBERS = 16
+RTK_ABI_VERSION = 3
+
+
+class rtk_group_info(C.Structure):
+    _fields_ = [
+        ("n_members", C.c_uint32),
+        ("exchange", C.c_uint32),
+        ("root_share", C.c_uint32),
+        ("rows_mode", C.c_uint32),
+        ("messages", C.c_uint32),
+        ("reserved_", C.c_uint32),
+        ("bytes_into_root", C.c_uint64),
+        ("gather_ms", C.c_double),
+        ("share_tile_rows", C.c_uint32 * RTK_GROUP_INFO_MEMBERS),
+        ("share_ms", C.c_double * RTK_GROUP_INFO_MEMBERS),
+        ("share_rays", C.c_uint64 * RTK_GROUP_INFO_MEMBERS),
+    ]
+
+
 # Every symbol include/rtk.h declares: name -> (restype, argtypes).
 SYMBOLS = {
     "rtk_camera_init": (C.c_int, [C.POINTER(rtk_camera), C.c_uint32, C.c_uint32, C.c_double]),
@@ -198,6 +218,11 @@ SYMBOLS = {
     "rtk_group_band_tile_rows": (C.c_uint32, [C.c_void_p, C.c_uint32]),
     "rtk_group_set_bands_per_member": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rtk_group_exchange": (C.c_char_p, [C.c_void_p]),
+    "rtk_group_set_root_share": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rtk_group_set_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "rtk_group_balance": (C.c_int, [C.c_void_p, C.POINTER(rtk_camera), C.c_int, C.c_int, C.c_uint32, C.c_double]),
+    "rtk_group_get_info": (C.c_int, [C.c_void_p, C.POINTER(rtk_group_info)]),
+    "rtk_abi_version": (C.c_uint32, []),
     "rtk_set_trace_order": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64]),
     "rtk_last_error": (C.c_char_p, []),
     "rtk_version": (C.c_char_p, []),

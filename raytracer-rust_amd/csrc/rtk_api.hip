@@ -201,7 +201,9 @@ extern "C" {
 
 const char* rtk_last_error(void) { return g_error.c_str(); }
 
-const char* rtk_version(void) { return "rtk 0.1 (gfx950, HIP)"; }
+const char* rtk_version(void) { return "rtk 0.3 (gfx950, HIP)"; }
+
+uint32_t rtk_abi_version(void) { return RTK_ABI_VERSION; }
 
 int rtk_camera_init(rtk_camera* camera, uint32_t width, uint32_t height, double fov) {
   if (!camera || width == 0 || height == 0) return fail(RTK_ERR_INVALID, "rtk_camera_init: null camera or zero size");
@@ -1174,12 +1176,18 @@ int rtk::partition_from_tiling(const rtk_camera* camera, const rtk_tiling* tilin
   return RTK_OK;
 }
 
+// Of `rows` tile rows, those in k * period + [offset, offset + width), k = 0, 1, ...
+uint64_t rtk::rows_of_share(uint32_t rows, uint32_t period, uint32_t offset, uint32_t width) {
+  if (period == 0 || width == 0) return 0;
+  const uint64_t whole = rows / period, rest = rows % period;
+  return whole * width + (rest > offset ? std::min<uint64_t>(width, rest - offset) : 0u);
+}
 // Tile rows of [first, first + n) that the bands dealt to `rank` hold.
 static uint64_t band_rows_of_rank(uint32_t rows, uint32_t m, uint32_t rank, uint32_t world) {
-  const uint32_t bands = (rows + m - 1) / m;
-  uint64_t mine = 0;
-  for (uint32_t b = rank; b < bands; b += world) mine += std::min(m, rows - b * m);
-  return mine;
+  const uint64_t period = (uint64_t)m * world, offset = (uint64_t)m * rank;
+  if (offset >= rows) return 0;
+  if (period >= rows) return std::min<uint64_t>(m, rows - offset);  // a single round
+  return rtk::rows_of_share(rows, (uint32_t)period, (uint32_t)offset, m);
 }
 static bool banding_rows(uint32_t height, const rtk_banding* bd, uint32_t& rows) {
   if (!bd || bd->world == 0 || bd->rank >= bd->world || bd->band_tile_rows == 0) return false;
@@ -1199,11 +1207,28 @@ int rtk::partition_from_banding(const rtk_camera* camera, const rtk_banding* ban
     return fail(RTK_ERR_INVALID, std::string(who) + ": bad banding (rank >= world, band_tile_rows == 0, or rows outside the frame)");
   p = rtk::Partition{};
   p.layout = banding->compact ? 2u : 0u;
+  // a period or an offset beyond 32 bits lies beyond the frame: one round, or no rows at all
+  const uint64_t period = (uint64_t)banding->band_tile_rows * banding->world, offset = (uint64_t)banding->band_tile_rows * banding->rank;
   p.band_rows = banding->band_tile_rows;
-  p.band_world = banding->world;
-  p.band_rank = banding->rank;
+  p.band_period = (uint32_t)std::min<uint64_t>(period, 0xffffffffull);
+  p.band_offset = offset > 0xffffffffull ? 0u : (uint32_t)offset;
   p.row0 = banding->first_tile_row;
   p.n_local_tiles = band_rows_of_rank(rows, banding->band_tile_rows, banding->rank, banding->world) * tiles_across(camera->width);
+  return RTK_OK;
+}
+
+int rtk::partition_from_rows(const rtk_camera* camera, uint32_t first, uint32_t period, uint32_t offset, uint32_t width,
+                             bool compact, rtk::Partition& p, const char* who) {
+  const uint32_t ty = tiles_down(camera->height);
+  if (first > ty || width == 0 || period == 0 || (uint64_t)offset + width > period)
+    return fail(RTK_ERR_INVALID, std::string(who) + ": bad share of the frame's tile rows");
+  p = rtk::Partition{};
+  p.layout = compact ? 2u : 0u;
+  p.band_rows = width;
+  p.band_period = period;
+  p.band_offset = offset;
+  p.row0 = first;
+  p.n_local_tiles = rtk::rows_of_share(ty - first, period, offset, width) * tiles_across(camera->width);
   return RTK_OK;
 }
 
@@ -1345,7 +1370,7 @@ static int frame_launch(Frame& f, const rtk::Partition& p, float* d_rgb_f32, uin
   t.n_local_tiles = (uint32_t)p.n_local_tiles;
   t.layout = p.layout;
   t.step = p.step, t.offset = p.offset;
-  t.band_rows = p.band_rows, t.band_world = p.band_world, t.band_rank = p.band_rank, t.row0 = p.row0;
+  t.band_rows = p.band_rows, t.band_period = p.band_period, t.band_offset = p.band_offset, t.row0 = p.row0;
   rtk_context* ctx = f.ctx;
   if (f.opaque) {
     if (split) ctx->ev_split[f.slot] = true;
@@ -1403,6 +1428,11 @@ static int render_device(rtk_context* ctx, rtk_scene_handle* scene, const rtk_ca
   ResolveStep step = resolve;
   step.n_tiles = p.n_local_tiles;
   return frame_end(f, step, d_rgb_f32);
+}
+
+int rtk::render_device_partition(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, const rtk::Partition& p,
+                                 float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream) {
+  return render_device(ctx, scene, camera, p, d_rgb_f32, d_rgba8, hip_stream, ResolveStep{});
 }
 
 extern "C" {

@@ -192,12 +192,15 @@ struct RenderTarget {
   uint32_t n_local_tiles;
   uint32_t layout;  // 0: row-major frame; 1: the rank's tiles one after the other (tile-major); 2: the rank's tile rows one after the other
   // Local tile k of the launch is entry g = k * step + offset of a row-major walk over tile rows
-  // of tiles_x tiles; row q = g / tiles_x of that walk is row q % band_rows of band q / band_rows,
-  // and that band is the global band (q / band_rows) * band_world + band_rank counted from tile row row0.
-  //   tiles dealt round-robin to `world` ranks: step = world, offset = rank, band_rows = 1, band_world = 1, band_rank = 0
-  //   bands of m tile rows dealt round-robin:   step = 1, offset = 0, band_rows = m, band_world = world, band_rank = rank
+  // of tiles_x tiles; row q = g / tiles_x of that walk is row q % band_rows of the launch's band
+  // q / band_rows, and that band starts at tile row row0 + (q / band_rows) * band_period + band_offset:
+  // the launch owns band_rows tile rows out of every band_period, from band_offset on.
+  //   tiles dealt round-robin to `world` ranks: step = world, offset = rank, band_rows = 1, band_period = 1, band_offset = 0
+  //   bands of m tile rows dealt round-robin:   step = 1, offset = 0, band_rows = m, band_period = world * m, band_offset = rank * m
+  //   a rank that holds a of every v bands:     band_rows = a * m, band_period = v * m, band_offset = (its first band) * m
+  //   one run of rows [r0, r0 + n):             band_rows = n, band_period = n, band_offset = 0, row0 = r0
   uint32_t step, offset;
-  uint32_t band_rows, band_world, band_rank, row0;
+  uint32_t band_rows, band_period, band_offset, row0;
 };
 
 struct TileRef {
@@ -209,7 +212,7 @@ __device__ __forceinline__ TileRef tile_ref(const RenderTarget& T, uint32_t k) {
   const uint32_t g = k * T.step + T.offset;
   r.tx = g % T.tiles_x;
   r.lrow = g / T.tiles_x;
-  r.ty = T.row0 + ((r.lrow / T.band_rows) * T.band_world + T.band_rank) * T.band_rows + r.lrow % T.band_rows;
+  r.ty = T.row0 + (r.lrow / T.band_rows) * T.band_period + T.band_offset + r.lrow % T.band_rows;
   return r;
 }
 

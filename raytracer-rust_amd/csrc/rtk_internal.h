@@ -133,11 +133,22 @@ int place_scene(rtk_context* ctx, const FlatScene& flat, rtk_scene_handle** out,
 struct Partition {
   uint32_t layout = 0;  // 0 frame, 1 tile-major compact, 2 the rank's tile rows one after the other
   uint32_t step = 1, offset = 0;
-  uint32_t band_rows = 1, band_world = 1, band_rank = 0, row0 = 0;
+  uint32_t band_rows = 1, band_period = 1, band_offset = 0, row0 = 0;
   uint64_t n_local_tiles = 0;
 };
 int partition_from_tiling(const rtk_camera* camera, const rtk_tiling* tiling, Partition& p, const char* who);
 int partition_from_banding(const rtk_camera* camera, const rtk_banding* banding, Partition& p, const char* who);
+// The tile rows first + k * period + [offset, offset + width), k = 0, 1, ..., clipped to the frame
+// (width >= 1, offset + width <= period); compact: the outputs hold only these rows, one after the
+// other, else whole frames.  What a group member with a share of its own renders.
+int partition_from_rows(const rtk_camera* camera, uint32_t first, uint32_t period, uint32_t offset, uint32_t width, bool compact,
+                        Partition& p, const char* who);
+// Tile rows of such a partition (all of them, or those that lie above tile row `before`).
+uint64_t rows_of_share(uint32_t rows, uint32_t period, uint32_t offset, uint32_t width);
+
+// rtk_render_device for an arbitrary partition of the frame (one sample per pixel).
+int render_device_partition(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, const Partition& p,
+                            float* d_rgb_f32, uint8_t* d_rgba8, void* hip_stream);
 
 }  // namespace rtk
 

@@ -53,6 +53,46 @@ class DeviceGroup:
         """About how many bands of a frame each member renders; 0 for the library's choice."""
         _device._check(_device.library().rtk_group_set_bands_per_member(self.group, int(bands)))
 
+    def set_root_share(self, root_share):
+        """The root holds `root_share` of every `members - 1 + root_share` bands (its rows do not travel)."""
+        _device._check(_device.library().rtk_group_set_root_share(self.group, int(root_share)))
+
+    def set_rows(self, height, first_tile_rows):
+        """One run of tile rows per member: member r renders [first_tile_rows[r], first_tile_rows[r + 1]);
+        None goes back to bands."""
+        if first_tile_rows is None:
+            _device._check(_device.library().rtk_group_set_rows(self.group, int(height), None))
+            return
+        rows = [int(v) for v in first_tile_rows]
+        if len(rows) != len(self) + 1:
+            raise ValueError("set_rows needs members + 1 boundaries")
+        arr = (C.c_uint32 * len(rows))(*rows)
+        _device._check(_device.library().rtk_group_set_rows(self.group, int(height), arr))
+
+    def balance(self, camera, want_rgb=True, want_rgba8=True, rounds=0, link_gbps=0.0):
+        """Lays one run of rows per member by measurement (rtk_group_balance); synchronises."""
+        cam = camera.to_abi() if hasattr(camera, "to_abi") else camera
+        _device._check(_device.library().rtk_group_balance(self.group, C.byref(cam), int(bool(want_rgb)), int(bool(want_rgba8)),
+                                                           int(rounds), float(link_gbps)))
+
+    def info(self):
+        """The last frame in numbers: messages, bytes into the root, each member's rows, kernel time and rays."""
+        info = abi.rtk_group_info()
+        _device._check(_device.library().rtk_group_get_info(self.group, C.byref(info)))
+        n = min(info.n_members, abi.RTK_GROUP_INFO_MEMBERS)
+        return {
+            "members": int(info.n_members),
+            "exchange": ("none", "rccl", "peer copies")[info.exchange],
+            "root_share": int(info.root_share),
+            "partition": "rows" if info.rows_mode else "bands",
+            "messages": int(info.messages),
+            "bytes_into_root": int(info.bytes_into_root),
+            "gather_ms": float(info.gather_ms),
+            "share_tile_rows": [int(info.share_tile_rows[r]) for r in range(n)],
+            "share_ms": [float(info.share_ms[r]) for r in range(n)],
+            "share_rays": [int(info.share_rays[r]) for r in range(n)],
+        }
+
     def render_device(self, camera, want_rgb=True, want_rgba8=True, out_rgb=None, out_rgba8=None):
         """Queues one frame; returns ([H, W, 3] float32, [H, W, 4] uint8) tensors on the root's device.
         Asynchronous on torch's current stream of that device."""

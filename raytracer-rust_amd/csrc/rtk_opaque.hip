@@ -48,6 +48,17 @@
 
 namespace rtk {
 
+// Experiment builds (-DRTK_COUNT_EVENT=n): the exact-test counter counts one kind of event of the fused
+// kernel instead -- 1 level-0 rounds, 2 opened clusters, 3 level-2 spheres, 4 exact-test visits of the
+// shadow phase (per wavefront, not per lane); 5 exact-test visits, 6 level-2 spheres, 7 opened clusters
+// of the camera phase.
+#ifdef RTK_COUNT_EVENT
+#define RTK_EVENT(n, wc) do { if (RTK_COUNT_EVENT == (n)) (wc).exact += 1u; } while (0)
+#define RTK_EXACT(wc, n) do { if (RTK_COUNT_EVENT == 0) (wc).exact += (n); } while (0)
+#else
+#define RTK_EVENT(n, wc) do { } while (0)
+#define RTK_EXACT(wc, n) do { (wc).exact += (n); } while (0)
+#endif
 
 // Hides a value from the optimiser so that what is computed from it is recomputed where
 // it is used instead of being kept live across a sweep.
@@ -167,10 +178,12 @@ __device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera
     for (; cm != 0ull; cm &= cm - 1ull) {
       const uint32_t first = (cbase + (uint32_t)__builtin_ctzll(cm)) * kBundle;
       if (first >= S.n_spheres_padded) break;  // cannot happen (padding clusters never pass); keeps a slip from reading out of bounds
+      RTK_EVENT(7, wc);
       // level 1: this lane's sphere of the cluster against the cone
       unsigned long long m = __builtin_amdgcn_ballot_w64(cone_reaches(cone, prim_ball[first + lane]));
       // level 2: per-ray filter and exact test for the spheres level 1 kept
       for (; m != 0ull; m &= m - 1ull) {
+        RTK_EVENT(6, wc);
         const uint32_t j = first + (uint32_t)__builtin_ctzll(m);
         const float4 r = prim[j];
         float t = r.x * dx;
@@ -179,7 +192,8 @@ __device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera
         const bool pass = px.valid && __builtin_fmaf(t, t, -r.w) >= 0.0f;
         const unsigned n_pass = lanes_where(pass);
         if (n_pass) {
-          wc.exact += n_pass;
+          RTK_EXACT(wc, n_pass);
+          RTK_EVENT(5, wc);
           const RTK_RO SphRecord& rec = S.sph_record[j];
           if (pass) {
             double t0, t1;
@@ -455,12 +469,14 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
     bool wave_live = wave_any(live);
     for (uint32_t cbase = 0; wave_live && cbase < S.n_clusters_padded; cbase += kBundle) {
       // level 0: this lane's cluster against the patch's line bundles
+      RTK_EVENT(1, wc);
       const float4 cl = S.cluster_ball[cbase + lane];
       unsigned long long cm = __builtin_amdgcn_ballot_w64(lines_reach(cl, cl.w, S.r_max));
       for (; wave_live && cm != 0ull; cm &= cm - 1ull) {
         const uint32_t first = (cbase + (uint32_t)__builtin_ctzll(cm)) * kBundle;
         if (first >= S.n_spheres_padded) break;  // cannot happen (padding clusters never pass); keeps a slip from reading out of bounds
         // level 1: this lane's sphere of the cluster
+        RTK_EVENT(2, wc);
         const float4 rec = S.sph_ball[first + lane];
         unsigned long long m = __builtin_amdgcn_ballot_w64(lines_reach(rec, 0.0f, rec.w));
         const unsigned long long plain = S.cluster_plain[first / kBundle];
@@ -468,6 +484,7 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
         // level 2: per-ray tabulated filter, then the exact test
         for (; m != 0ull; m &= m - 1ull) {
           const uint32_t member = (uint32_t)__builtin_ctzll(m), j = first + member;
+          RTK_EVENT(3, wc);
           const float4 c = S.sph_tab[j];
           const float pc = __builtin_fmaf(f.z, c.z, __builtin_fmaf(f.y, c.y, f.x * c.x));
           const float e = __builtin_fmaf(pc, kTwoKappa, -c.w);
@@ -496,7 +513,8 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
               const bool run = ((mask >> r) & 1u) != 0u;
               const unsigned n_run = lanes_where(run);
               if (n_run == 0u) continue;
-              wc.exact += n_run;
+              RTK_EXACT(wc, n_run);
+              RTK_EVENT(4, wc);
               if (run && shadow_ray_blocked(S, rec, S.lights[kb + r], p)) occl |= 1u << r;
             }
             changed = true;
@@ -689,7 +707,8 @@ __device__ __forceinline__ bool shadow_phase_bundled(const DevScene& S, bool nee
               const bool run = ((mask >> r) & 1u) != 0u;
               const unsigned n_run = lanes_where(run);
               if (n_run == 0u) continue;
-              wc.exact += n_run;
+              RTK_EXACT(wc, n_run);
+              RTK_EVENT(4, wc);
               if (run && shadow_ray_blocked(S, rec, S.lights[kb + r], p)) occl |= 1u << r;
             }
             changed = true;
@@ -798,7 +817,17 @@ __global__ void __launch_bounds__(64, 5) render_uniform_kernel(DevScene S, DevCa
     put3(stash.normal, g.normal);
     p = g.over;
   }
+#if defined(RTK_PHASES) && RTK_PHASES == 1  // experiment: the camera phase and the hit geometry only
+  store_patch(C, T, k, quarter, V3{best.t, p.x, p.y});
+  flush_counts(counters + (tile % kCounterShards), wc);
+  return;
+#endif
   const bool in_shadow = TABULATED ? shadow_phase_uniform<KW>(S, hit, p, wc) : shadow_phase_bundled<KW>(S, hit, p, wc);
+#if defined(RTK_PHASES) && RTK_PHASES == 2  // experiment: ... and the shadow phase
+  store_patch(C, T, k, quarter, V3{best.t, p.x, in_shadow ? 1.0 : 0.0});
+  flush_counts(counters + (tile % kCounterShards), wc);
+  return;
+#endif
   V3 color = {0, 0, 0};
   if (px.valid) color = hit ? shade_hit_stashed(S, launder(obj), in_shadow, &stash) : ld3(S.ambient);
   store_patch(C, T, k, quarter, color);

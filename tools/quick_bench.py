@@ -59,5 +59,5 @@ for name in names:
     nsph = sum(1 for n in scene.nodes if n.kind == 0)
     fl = 26 * nsph + 8 * (len(scene.nodes) - nsph)
     print(f"{name}: {best.kernel_ms:8.3f} ms  {best.rays / best.kernel_ms / 1e3:9.1f} Mrays/s  "
-          f"{100 * best.rays * fl / (best.kernel_ms * 1e-3) / 157.3e12:6.1f}% of FP32 peak (algorithmic)  exact/ray-test {best.exact_tests / (best.rays * max(nsph,1)):.2e}  rays {best.rays_primary}+{best.rays_secondary}+{best.rays_shadow}", flush=True)
+          f"{100 * best.rays * fl / (best.kernel_ms * 1e-3) / 157.3e12:6.1f}% of FP32 peak (algorithmic)  exact/ray-test {best.exact_tests / (best.rays * max(nsph,1)):.2e}  rays {best.rays_primary}+{best.rays_secondary}+{best.rays_shadow}  exact_tests {best.exact_tests}", flush=True)
     h.release()

@@ -172,6 +172,9 @@ __device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera
   if (!wave_any(px.valid)) return;
   // pixels outside the frame still have well-defined directions; they only widen the cone a little
   const Cone cone = make_cone(dx, dy, dz);
+#if defined(RTK_PHASES) && RTK_PHASES == 5  // experiment: the camera phase without its sweep (phases1 otherwise)
+  if (cone.tan_t + cone.sec_t + cone.ax != 12345.678f) return;
+#endif
   for (uint32_t cbase = 0; cbase < S.n_clusters_padded; cbase += kBundle) {
     // level 0: this lane's cluster against the cone
     unsigned long long cm = __builtin_amdgcn_ballot_w64(cone_reaches(cone, prim_cluster[cbase + lane]));
@@ -236,7 +239,7 @@ __device__ __forceinline__ V3 over_point(const DevScene& S, const DevCamera& C, 
 __device__ __forceinline__ bool shadow_ray_blocked(const RTK_RO DevObject& ob, const RTK_RO DevLight& L, V3 p) {
   V3 lv = ld3(L.pos) - p;
   const double lw = L.pos[3] - 1.0;
-  const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+  const double m = sqrt_f64(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
   double dw;
   const V3 d = divide_by_length(lv, lw, m, dw);
   double t0, t1;
@@ -248,7 +251,7 @@ __device__ __forceinline__ bool shadow_ray_blocked(const RTK_RO DevObject& ob, c
 __device__ __forceinline__ bool shadow_ray_blocked(const DevScene& S, const RTK_RO SphRecord& rec, const RTK_RO DevLight& L, V3 p) {
   V3 lv = ld3(L.pos) - p;
   const double lw = L.pos[3] - 1.0;
-  const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+  const double m = sqrt_f64(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
   double dw;
   const V3 d = divide_by_length(lv, lw, m, dw);
   double t0, t1;
@@ -467,6 +470,9 @@ __device__ __forceinline__ bool shadow_phase_uniform(const DevScene& S, bool nee
     };
 
     bool wave_live = wave_any(live);
+#if defined(RTK_PHASES) && RTK_PHASES == 3  // experiment: the shadow phase's set-up and accounting without its sweep
+    wave_live = wave_live && Q1 + Q3 + pad + f.thrp + lgrow[0] == 12345.678f;
+#endif
     for (uint32_t cbase = 0; wave_live && cbase < S.n_clusters_padded; cbase += kBundle) {
       // level 0: this lane's cluster against the patch's line bundles
       RTK_EVENT(1, wc);
@@ -777,6 +783,9 @@ __device__ __forceinline__ V3 shade_hit_stashed(const DevScene& S, uint32_t obj,
   const V3 objp = xform(ob.inv, over, 1.0);  // as LightingData computes it (src/scene/lighting.rs:52)
   const V3 tex = sample_texture_at(S, ob, obj, objp);
   V3 surface = ld3(S.ambient);
+#if defined(RTK_PHASES) && RTK_PHASES == 4  // experiment: shading without the sum over the lights
+  return surface + tex + normal + eye;
+#endif
   for (uint32_t l = 0; l < S.n_lights; ++l)
     surface = surface + phong_lighting(S.lights[l], ob, tex, over, eye, normal, in_shadow);
   return surface;
@@ -817,7 +826,7 @@ __global__ void __launch_bounds__(64, 5) render_uniform_kernel(DevScene S, DevCa
     put3(stash.normal, g.normal);
     p = g.over;
   }
-#if defined(RTK_PHASES) && RTK_PHASES == 1  // experiment: the camera phase and the hit geometry only
+#if defined(RTK_PHASES) && (RTK_PHASES == 1 || RTK_PHASES == 5)  // experiment: the camera phase and the hit geometry only
   store_patch(C, T, k, quarter, V3{best.t, p.x, p.y});
   flush_counts(counters + (tile % kCounterShards), wc);
   return;

@@ -264,7 +264,7 @@ __device__ __forceinline__ bool shadow_by_sweeps(const DevScene& S, bool active,
           if (!plane_may_block(side, S.plane_light[ip * S.n_lights + kb + r])) continue;
           V3 lv = ld3(L.pos) - p;
           double lw = L.pos[3] - 1.0;
-          double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+          double m = sqrt_f64(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
           double dw;
           V3 d = divide_by_length(lv, lw, m, dw);
           double t0, t1;
@@ -297,7 +297,7 @@ __device__ __forceinline__ bool shadow_by_sweeps(const DevScene& S, bool active,
         const RTK_RO DevLight& L = S.lights[kb + r];
         V3 lv = ld3(L.pos) - p;
         double lw = L.pos[3] - 1.0;
-        double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+        double m = sqrt_f64(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
         double dw;
         V3 d = divide_by_length(lv, lw, m, dw);
         double t0, t1;
@@ -357,7 +357,7 @@ __device__ __forceinline__ bool shadow_by_grids(const DevScene& S, bool active, 
     // the reference's shadow ray towards this light (src/scene.rs:208-225)
     const V3 lv = ld3(L.pos) - p;
     const double lw = L.pos[3] - 1.0;
-    const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+    const double m = sqrt_f64(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
     double dw;
     const V3 d = divide_by_length(lv, lw, m, dw);
     wc.shadow += lanes_where(need);

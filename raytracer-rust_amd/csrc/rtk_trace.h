@@ -109,7 +109,7 @@ __device__ __forceinline__ bool shadow_brute(const DevScene& S, bool active, V3 
       const RTK_RO DevLight& L = S.lights[k];
       const V3 lv = ld3(L.pos) - p;
       const double lw = L.pos[3] - 1.0;
-      const double m = sqrt(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+      const double m = sqrt_f64(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
       double dw;
       const V3 d = divide_by_length(lv, lw, m, dw);
       for (uint32_t obj = 0; obj < S.n_objects; ++obj) {
@@ -150,7 +150,7 @@ __device__ __forceinline__ void emit_children(const DevScene& S, const RTK_RO De
     double n_ratio = n1 / n2;
     double sin_t2 = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
     if (!(sin_t2 > 1.0)) {
-      double cos_t = sqrt(1.0 - sin_t2);
+      double cos_t = sqrt_f64(1.0 - sin_t2);
       V3 dir = g.normal * (n_ratio + cos_i - cos_t) - g.eye * n_ratio;  // the reference's `+`
       if (child_traces)
         sink.child(false, g.under, dir, w_refr, depth + 1);

@@ -420,6 +420,13 @@ typedef struct rtk_group_info {
 } rtk_group_info;
 int rtk_group_get_info(rtk_group* group, rtk_group_info* info);
 
+/* Flattens a scene as rtk_scene_upload would -- validation, inverses, sweep order, every record
+ * array -- WITHOUT touching a device, and returns a 64-bit digest of the result (and, if asked, the
+ * bytes the scene would take in HBM).  No counterpart in the reference; it exists so that the host
+ * half of the library can be checked without a GPU: two builds, or two threads, that flatten one
+ * scene must agree on the digest. */
+int rtk_flatten_digest(const rtk_scene* scene, uint64_t* digest, uint64_t* device_bytes);
+
 /* Thread-local description of the last failure on this thread ("" if none). */
 const char* rtk_last_error(void);
 

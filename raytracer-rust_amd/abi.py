@@ -223,6 +223,7 @@ SYMBOLS = {
     "rtk_group_balance": (C.c_int, [C.c_void_p, C.POINTER(rtk_camera), C.c_int, C.c_int, C.c_uint32, C.c_double]),
     "rtk_group_get_info": (C.c_int, [C.c_void_p, C.POINTER(rtk_group_info)]),
     "rtk_abi_version": (C.c_uint32, []),
+    "rtk_flatten_digest": (C.c_int, [C.POINTER(rtk_scene), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rtk_set_trace_order": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64]),
     "rtk_last_error": (C.c_char_p, []),
     "rtk_version": (C.c_char_p, []),

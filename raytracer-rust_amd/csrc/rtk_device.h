@@ -1,9 +1,15 @@
-// rtk_device.h -- data layout shared by the host side (rtk_api.hip) and the kernels
+// rtk_device.h -- data layout shared by the host side (rtk_host.cpp, rtk_api.hip) and the kernels
 // (rtk_kernels.hip, rtk_opaque.hip).  Everything here lives in HBM and is read-only during a render.
+// Host code that is not compiled by hipcc (rtk_host.cpp) sees the same structs: the vector types come
+// from HIP's header of plain structs, which needs neither the runtime nor a device compiler.
 #ifndef RTK_DEVICE_H
 #define RTK_DEVICE_H
 
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#else
+#include <hip/hip_vector_types.h>
+#endif
 #include <stdint.h>
 
 namespace rtk {
@@ -147,7 +153,9 @@ constexpr uint32_t kPersistentGroups = 2048;  // workgroups of such a launch at 
 struct DevCounters {
   unsigned long long rays_primary, rays_shadow, rays_secondary, exact_tests;
 };
+#if defined(__HIPCC__)
 __device__ __forceinline__ DevCounters* counter_shard(DevCounters* base) { return base + (blockIdx.x % kCounterShards); }
+#endif
 
 // Level-by-level tracing of scenes with secondary rays (rtk_wavefront.hip): a queued ray, what
 // its node contributes, and the buffers of a context.  Node i of a pass is a camera ray for
@@ -207,6 +215,7 @@ struct TileRef {
   uint32_t tx, ty;  // tile coordinates in the frame
   uint32_t lrow;    // row of the launch's own walk (the local tile row in band mode)
 };
+#if defined(__HIPCC__)
 __device__ __forceinline__ TileRef tile_ref(const RenderTarget& T, uint32_t k) {
   TileRef r;
   const uint32_t g = k * T.step + T.offset;
@@ -215,6 +224,7 @@ __device__ __forceinline__ TileRef tile_ref(const RenderTarget& T, uint32_t k) {
   r.ty = T.row0 + (r.lrow / T.band_rows) * T.band_period + T.band_offset + r.lrow % T.band_rows;
   return r;
 }
+#endif
 
 }  // namespace rtk
 #endif

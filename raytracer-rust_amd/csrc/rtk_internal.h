@@ -1,21 +1,14 @@
-// rtk_internal.h -- what the host-side translation units of the library share: the opaque
-// handles of include/rtk.h, error reporting, and the single-device render call the multi-device
-// code is built on.  Host code only.
+// rtk_internal.h -- what the device-side translation units of the host code share (rtk_api.hip,
+// rtk_group.hip): the context, HIP error reporting, placing a flattened scene on a device, and the
+// single-device render call the multi-device code is built on.  Host code only.
 #ifndef RTK_INTERNAL_H
 #define RTK_INTERNAL_H
 
-#include "../../include/rtk.h"
-#include "rtk_device.h"
+#include "rtk_host.h"
 #include "rtk_kernels.h"
-
-#include <memory>
-#include <string>
-#include <vector>
 
 namespace rtk {
 
-// Sets the thread's error text (rtk_last_error) and returns `code`.
-int fail(int code, const std::string& msg);
 int fail_hip(hipError_t e, const char* what);
 
 }  // namespace rtk
@@ -25,37 +18,6 @@ int fail_hip(hipError_t e, const char* what);
     hipError_t e_ = (call);                                \
     if (e_ != hipSuccess) return rtk::fail_hip(e_, #call); \
   } while (0)
-
-// A scene resident in HBM: one device allocation, the pointers into it, and the argument block
-// the kernels take.
-struct rtk_scene_handle {
-  rtk::DevScene dev{};
-  void* d_block = nullptr;  // the one device allocation every pointer below points into
-  size_t block_bytes = 0;   // its size
-  void* d_objects = nullptr;
-  void* d_lights = nullptr;
-  void* d_filter = nullptr;
-  void* d_exact = nullptr;
-  void* d_sph_object = nullptr;
-  void* d_sph_record = nullptr;
-  void* d_plane_object = nullptr;
-  void* d_plane_light = nullptr;
-  void* d_light_kind = nullptr;
-  void* d_pattern_inv = nullptr;
-  void* d_prim = nullptr;          // camera-ray filter records (rebuilt per camera)
-  void* d_prim_ball = nullptr;     // camera-ray records of the wavefront-level cone test (rebuilt per camera)
-  void* d_sph_ball = nullptr;
-  void* d_cluster_ball = nullptr;
-  void* d_super_ball = nullptr;
-  void* d_cluster_plain = nullptr;
-  void* d_light_grid = nullptr;
-  void* d_grid_cells = nullptr;
-  void* d_grid_entries = nullptr;
-  void* d_prim_cluster = nullptr;  // camera-ray records of the cluster balls (rebuilt per camera)
-  void* d_light_filter = nullptr;
-  void* d_k_table = nullptr;
-  void* d_sph_tab = nullptr;
-};
 
 struct rtk_context {
   int device = -1;
@@ -103,48 +65,11 @@ struct rtk_context {
 
 namespace rtk {
 
-// A scene flattened for the device, not yet on one: the bytes of the record arrays laid out as
-// they will lie in the device allocation, and the kernels' argument block with its pointers unset.
-struct FlatScene {
-  struct Piece {
-    void* rtk_scene_handle::*dst;
-    size_t bytes, offset;
-  };
-  std::vector<Piece> pieces;
-  unsigned char* staged = nullptr;  // the first `staged_bytes` bytes of the allocation
-  size_t staged_bytes = 0;
-  std::vector<unsigned char> extra;  // bytes that follow the staged ones in the allocation, built apart from them
-  size_t total = 0;                 // allocation size (the per-camera records follow the staged part and the extra bytes)
-  DevScene dev{};
-  // Where the staged bytes live: memory from `grow` (e.g. a context's page-locked staging buffer,
-  // which must hold at least the asked-for bytes until the scene has been placed), else `own`.
-  unsigned char* (*grow)(void* user, size_t bytes) = nullptr;
-  void* user = nullptr;
-  std::unique_ptr<unsigned char[]> own;
-};
-// Validation and flattening (host work only); RTK_OK or an rtk_status with the error text set.
-int flatten_scene(const rtk_scene* scene, FlatScene& out);
 // Allocates on ctx's device, copies, and fills a new handle.  With `reuse` (a handle of ctx that no
 // work in flight uses any more): its allocation takes the scene when it is large enough, and it is
 // released otherwise; either way `reuse` must not be used again.
 int place_scene(rtk_context* ctx, const FlatScene& flat, rtk_scene_handle** out, rtk_scene_handle* reuse = nullptr);
 
-// Which tiles of the frame a launch renders and where they go: the host-side form of RenderTarget.
-struct Partition {
-  uint32_t layout = 0;  // 0 frame, 1 tile-major compact, 2 the rank's tile rows one after the other
-  uint32_t step = 1, offset = 0;
-  uint32_t band_rows = 1, band_period = 1, band_offset = 0, row0 = 0;
-  uint64_t n_local_tiles = 0;
-};
-int partition_from_tiling(const rtk_camera* camera, const rtk_tiling* tiling, Partition& p, const char* who);
-int partition_from_banding(const rtk_camera* camera, const rtk_banding* banding, Partition& p, const char* who);
-// The tile rows first + k * period + [offset, offset + width), k = 0, 1, ..., clipped to the frame
-// (width >= 1, offset + width <= period); compact: the outputs hold only these rows, one after the
-// other, else whole frames.  What a group member with a share of its own renders.
-int partition_from_rows(const rtk_camera* camera, uint32_t first, uint32_t period, uint32_t offset, uint32_t width, bool compact,
-                        Partition& p, const char* who);
-// Tile rows of such a partition (all of them, or those that lie above tile row `before`).
-uint64_t rows_of_share(uint32_t rows, uint32_t period, uint32_t offset, uint32_t width);
 
 // rtk_render_device for an arbitrary partition of the frame (one sample per pixel).
 int render_device_partition(rtk_context* ctx, rtk_scene_handle* scene, const rtk_camera* camera, const Partition& p,

@@ -1,0 +1,115 @@
+"""The host half of the library (csrc/rtk_host.cpp: validation, the reference's matrix arithmetic, scene
+flattening, camera and partition arithmetic) under AddressSanitizer + UndefinedBehaviorSanitizer and under
+ThreadSanitizer, without a GPU.
+
+`make -C raytracer-rust_amd/csrc asan tsan` builds that file with g++ and the sanitizers together with
+tests/host/host_check.cpp, a driver that flattens every scene it is given once on its main thread and then
+from eight threads at once, and checks its argument handling and arithmetic.  The scenes here are the large
+benchmark scene, its glass variant (light grids), the bundled scene and randomised scenes; every digest the
+sanitizer builds print must equal the one the shipped library (librtk.so, same source file) computes for the
+same scene through `rtk_flatten_digest`.
+"""
+import ctypes as C
+import importlib
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "raytracer-rust_amd", "csrc")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def dump_scene(rtk, scene, path):
+    s = scene.to_abi()
+    with open(path, "wb") as f:
+        f.write(b"RTKS" + struct.pack("<III", s.n_objects, s.n_lights, s.max_depth) + struct.pack("<3d", *s.ambient_color))
+        f.write(C.string_at(s.objects, s.n_objects * C.sizeof(rtk.abi.rtk_object)) if s.n_objects else b"")
+        f.write(C.string_at(s.lights, s.n_lights * C.sizeof(rtk.abi.rtk_light)) if s.n_lights else b"")
+    return s
+
+
+@pytest.fixture(scope="module")
+def scenes(tmp_path_factory):
+    rtk = importlib.import_module("raytracer-rust_amd")
+    from fuzz_parity import random_scene
+
+    out = tmp_path_factory.mktemp("scenes")
+    named = {
+        "c4": rtk.synthetic.config("C4", 64, 36)[0],
+        "c4_glass": rtk.synthetic.make_scene(10000, True, 4, 0xC0FFEE00 + 10000, glass=True),
+        "c2g": rtk.synthetic.config("C2g", 64, 36)[0],
+        "bundled": rtk.PackedScene.from_yaml_file(os.path.join(ROOT, "tests", "golden", "test01.yaml")).build(),
+    }
+    for seed in (7001, 7002, 7003, 7004, 7005, 7006):
+        named[f"fuzz{seed}"] = random_scene(rtk, np.random.default_rng(seed))[0]
+    files, keep = {}, []
+    for name, scene in named.items():
+        path = str(out / f"{name}.bin")
+        keep.append(dump_scene(rtk, scene, path))
+        files[name] = path
+    return rtk, files, dict(zip(named, keep))
+
+
+def library_digests(rtk, abi_scenes):
+    lib = importlib.import_module("raytracer-rust_amd.device").library()
+    out = {}
+    for name, s in abi_scenes.items():
+        digest, nbytes = C.c_uint64(), C.c_uint64()
+        assert lib.rtk_flatten_digest(C.byref(s), C.byref(digest), C.byref(nbytes)) == 0, lib.rtk_last_error()
+        out[name] = (digest.value, nbytes.value)
+    return out
+
+
+@pytest.mark.parametrize("target,binary,marker", [
+    ("asan", "host_check_asan", "ERROR: AddressSanitizer"),
+    ("tsan", "host_check_tsan", "WARNING: ThreadSanitizer"),
+])
+def test_host_half_under_sanitizers(scenes, target, binary, marker):
+    rtk, files, abi_scenes = scenes
+    r = subprocess.run(["make", "-C", CSRC, target], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
+               TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1")
+    env.pop("LD_PRELOAD", None)  # the sanitizer runtime must come first in the driver's own process
+    r = subprocess.run([os.path.join(CSRC, binary), "--threads", "8", "--repeats", "2"] + list(files.values()),
+                       capture_output=True, text=True, timeout=900, env=env)
+    report = r.stdout[-3000:] + r.stderr[-6000:]
+    assert r.returncode == 0 and "HOST_CHECK_OK" in r.stdout, report
+    assert marker not in r.stderr and "runtime error:" not in r.stderr, report
+    want = library_digests(rtk, abi_scenes)
+    got = {}
+    for line in r.stdout.splitlines():
+        if line.startswith("scene "):
+            _, path, _, digest, _, nbytes = line.split()
+            got[path] = (int(digest, 16), int(nbytes))
+    for name, path in files.items():
+        assert got[path] == want[name], (name, got[path], want[name])
+
+
+def test_flatten_digest_from_several_threads_in_the_library(scenes):
+    """The shipped library itself: one scene flattened from eight Python threads at once (ctypes releases the
+    interpreter lock around the call) gives one digest."""
+    import threading
+
+    rtk, _, abi_scenes = scenes
+    lib = importlib.import_module("raytracer-rust_amd.device").library()
+    s = abi_scenes["c4_glass"]
+    want = library_digests(rtk, {"x": s})["x"]
+    results = []
+
+    def work():
+        digest, nbytes = C.c_uint64(), C.c_uint64()
+        rc = lib.rtk_flatten_digest(C.byref(s), C.byref(digest), C.byref(nbytes))
+        results.append((rc, digest.value, nbytes.value))
+
+    threads = [threading.Thread(target=work) for _ in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert results == [(0,) + want] * 8

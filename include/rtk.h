@@ -228,7 +228,11 @@ int rtk_render_device_bands(rtk_context* ctx, rtk_scene_handle* scene, const rtk
  * RTK_STATIC_MAX_SPHERES spheres in the scene; at most RTK_STATIC_MAX_RECORD_PIXELS pixels per
  * call for scenes that need hit records (split larger frames with `tiling`).  Every call on a
  * GPU, from whatever context, shares that GPU's array: calls that overlap on one GPU race.
- * Calls of ONE context are ordered by the library like all its render calls. */
+ * Calls of ONE context are ordered by the library like all its render calls.
+ * While hip_stream is recording a HIP graph (hipStreamBeginCapture) the call only adds its kernels
+ * and its counter reset to the graph: it records no timing events and does not become the call
+ * rtk_get_stats and rtk_get_timing_history describe, and it is not ordered against the context's
+ * frames outside the graph (which share the records it rebuilds): that ordering is the caller's. */
 #define RTK_STATIC_MAX_SPHERES 32768u
 #define RTK_STATIC_MAX_RECORD_PIXELS 131072u
 #define RTK_STATIC_SCRATCH_BYTES (3u << 20)

@@ -38,7 +38,7 @@ using rtk::tiles_down;
 // ---------------------------------------------------------------- static scratch (rtk_render_device_static)
 // Device memory that exists without any allocation call: one array per GPU inside the library's
 // code object.  Layout (offsets in bytes), sized by the limits in include/rtk.h:
-//   counters      kCounterShards x DevCounters
+//   counters      kCounterSlots x DevCounters (the shards and the work counter behind them)
 //   prim          RTK_STATIC_MAX_SPHERES x float4     per-camera records of the per-ray filter
 //   prim_ball     RTK_STATIC_MAX_SPHERES x float4     ... of the wavefront-level cone test
 //   prim_cluster  RTK_STATIC_MAX_SPHERES / 64 x float4  ... of the cluster balls
@@ -319,6 +319,7 @@ struct Frame {
   hipStream_t st = nullptr;
   int slot = 0;
   bool opaque = false;
+  bool capturing = false;  // the stream is recording a HIP graph: no timing events, no bookkeeping of "the last call"
   Scratch scr;
 };
 
@@ -360,9 +361,22 @@ static const rtk::WavefrontBuffers* context_wavefront(rtk_context* ctx, size_t p
     w.nodes_per_pixel = std::min(w.nodes_per_pixel * 2u, (1u << rtk::kMaxDepth) - 1u);
   }
   const size_t floor_nodes = (size_t)rtk::kBlock * w.nodes_per_pixel;
-  const size_t want = std::min<size_t>(std::max<size_t>(pixels * w.nodes_per_pixel, floor_nodes), ctx->wavefront_max_nodes);
+  size_t want = std::min<size_t>(std::max<size_t>(pixels * w.nodes_per_pixel, floor_nodes), ctx->wavefront_max_nodes);
   if (want < floor_nodes) return nullptr;
-  if (w.cap_nodes >= want) return &w;
+  // the queue is kept while it fits the launch and is not more than eight times too large for it (a
+  // context that went from 4K frames to thumbnails gives the memory back)
+  if (w.cap_nodes >= want && w.cap_nodes / 8u <= want) return &w;
+  // never more than an eighth of the device memory that is free now: larger launches run in passes
+  // (128 bytes per node: a 1080p launch asks for 1.6 GB, a 4K launch for 6.4 GB, the cap is 8 GB)
+  size_t free_bytes = 0, total_bytes = 0;
+  if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
+    const size_t held = (size_t)w.cap_nodes * (sizeof(rtk::WfNodeRay) + sizeof(rtk::WfNodeOut));
+    want = std::min(want, (free_bytes + held) / 8u / (sizeof(rtk::WfNodeRay) + sizeof(rtk::WfNodeOut)));
+    if (want < floor_nodes) return nullptr;
+    if (w.cap_nodes >= want && w.cap_nodes / 8u <= want) return &w;
+  } else {
+    (void)hipGetLastError();
+  }
   // an earlier frame's kernels may still use the old buffers
   if (hipDeviceSynchronize() != hipSuccess) return nullptr;
   if (w.rays) (void)hipFree(w.rays);
@@ -391,10 +405,19 @@ static int frame_begin(Frame& f, rtk_context* ctx, rtk_scene_handle* scene, cons
   RTK_HIP(hipSetDevice(ctx->device));
   f.st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   f.opaque = !scene->dev.any_secondary;
-  if (ctx->n_timed && ctx->last_stream != f.st)
+  // A stream that is recording a graph takes the kernels as graph nodes.  An event recorded there
+  // cannot be waited on or read afterwards, and an event of work outside the graph cannot be waited on
+  // from inside it: such a call records no timing events and does not become "the context's last call"
+  // (rtk_get_stats keeps describing the last call made outside a capture); ordering the graph's launches
+  // against the context's other frames, which share the per-camera records and counters, is the caller's.
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  RTK_HIP(hipStreamIsCapturing(f.st, &capture));
+  f.capturing = capture != hipStreamCaptureStatusNone;
+  if (!f.capturing && ctx->n_timed && ctx->last_stream != f.st)
     RTK_HIP(hipStreamWaitEvent(f.st, ctx->ev_stop[(ctx->n_timed - 1) % RTK_TIMING_HISTORY], 0));
   RTK_HIP(rtk::launch_prep_primary(f.st, scene->dev, f.cam, f.scr.prim, f.scr.prim_ball, f.scr.prim_cluster, f.scr.counters));
   f.slot = (int)(ctx->n_timed % RTK_TIMING_HISTORY);
+  if (f.capturing) return RTK_OK;
   RTK_HIP(hipEventRecord(ctx->ev_start[f.slot], f.st));  // the per-camera record kernel (microseconds) stays outside
   ctx->ev_split[f.slot] = false;
   return RTK_OK;
@@ -416,6 +439,7 @@ static int frame_launch(Frame& f, const rtk::Partition& p, float* d_rgb_f32, uin
   t.step = p.step, t.offset = p.offset;
   t.band_rows = p.band_rows, t.band_period = p.band_period, t.band_offset = p.band_offset, t.row0 = p.row0;
   rtk_context* ctx = f.ctx;
+  if (f.capturing) split = false;
   if (f.opaque) {
     if (split) ctx->ev_split[f.slot] = true;
     RTK_HIP(rtk::launch_render_opaque(f.st, f.scene->dev, f.cam, f.scr.prim, f.scr.prim_ball, f.scr.prim_cluster, t,
@@ -432,6 +456,7 @@ static int frame_end(Frame& f, const ResolveStep& resolve, const float* d_sample
     RTK_HIP(rtk::launch_resolve_tiles(f.st, resolve.n_tiles, resolve.s, d_samples, resolve.d_rgb, resolve.d_rgba8));
   else if (resolve.s > 1)
     RTK_HIP(rtk::launch_resolve(f.st, resolve.width, resolve.height, resolve.s, d_samples, resolve.d_rgb, resolve.d_rgba8));
+  if (f.capturing) return RTK_OK;
   RTK_HIP(hipEventRecord(ctx->ev_stop[f.slot], f.st));
   ctx->last_stream = f.st;
   ctx->last_counters = f.scr.counters;
@@ -451,8 +476,10 @@ static int context_scratch(rtk_context* ctx, rtk_scene_handle* scene, size_t lau
     return context_records(ctx, launch_pixels, scr.opaque);
   }
   const rtk::DevScene& ds = scene->dev;
-  const bool by_level = ctx->trace_order == RTK_TRACE_BY_LEVEL ||
-                        (ctx->trace_order == RTK_TRACE_AUTO && rtk::wavefront_applies(ds) && rtk::wavefront_pays(ds, launch_pixels));
+  // (scenes of a handful of objects go to a kernel of their own before the queue is ever looked at)
+  const bool by_level = rtk::wavefront_applies(ds) &&
+                        (ctx->trace_order == RTK_TRACE_BY_LEVEL ||
+                         (ctx->trace_order == RTK_TRACE_AUTO && rtk::wavefront_pays(ds, launch_pixels)));
   if (by_level && ds.any_secondary && ds.max_depth >= 2 && ctx->wavefront_max_nodes) {
     RTK_HIP(hipSetDevice(ctx->device));
     scr.wavefront = context_wavefront(ctx, launch_pixels);

@@ -91,6 +91,69 @@ def test_static_scratch_with_hit_records_and_tiling(rtk, dev, device_mod):
     handle.release()
 
 
+def test_static_call_allocates_no_device_memory(rtk, dev, device_mod):
+    """Free device memory is the same before and after static calls with a scene and frame sizes the context
+    has not seen: everything they use beyond the caller's outputs lies in the library's static array."""
+    import torch
+
+    scene, camera = rtk.synthetic.config("C3", 1000, 700)
+    _, small = rtk.synthetic.config("C3", 333, 222)
+    handle = dev.upload(scene)
+    abi = importlib.import_module("raytracer-rust_amd.abi")
+    lib = device_mod.library()
+    outs = []
+    for cam in (camera, small):
+        c = cam.to_abi()
+        outs.append((c, torch.zeros((c.height, c.width, 3), dtype=torch.float32, device=dev.tdev),
+                     torch.zeros((c.height, c.width, 4), dtype=torch.uint8, device=dev.tdev)))
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for c, rgb, rgba in outs:
+        device_mod._check(lib.rtk_render_device_static(dev.ctx, handle.handle, C.byref(c), None, C.c_void_p(rgb.data_ptr()),
+                                                       C.c_void_p(rgba.data_ptr()), C.c_void_p(stream.cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
+    for (c, rgb, rgba), cam in zip(outs, (camera, small)):
+        want_rgb, want_rgba = dev.render_device(handle, cam)
+        torch.cuda.synchronize()
+        assert torch.equal(rgb, want_rgb) and torch.equal(rgba, want_rgba)
+    handle.release()
+
+
+def test_static_call_under_graph_capture(rtk, dev, device_mod):
+    """The call recorded into a HIP graph and replayed: the replay renders the frame; the capture leaves the
+    context's timing and statistics where the last call outside it put them."""
+    import torch
+
+    scene, camera = rtk.synthetic.config("C3", 640, 360)
+    handle = dev.upload(scene)
+    want_rgb, want_rgba = dev.render_device(handle, camera)
+    want_st = dev.stats()
+    torch.cuda.synchronize()
+    lib = device_mod.library()
+    cam = camera.to_abi()
+    rgb = torch.zeros((cam.height, cam.width, 3), dtype=torch.float32, device=dev.tdev)
+    rgba = torch.zeros((cam.height, cam.width, 4), dtype=torch.uint8, device=dev.tdev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        st = torch.cuda.current_stream(dev.tdev)
+        assert st.cuda_stream != 0
+        device_mod._check(lib.rtk_render_device_static(dev.ctx, handle.handle, C.byref(cam), None, C.c_void_p(rgb.data_ptr()),
+                                                       C.c_void_p(rgba.data_ptr()), C.c_void_p(st.cuda_stream)))
+    torch.cuda.synchronize()
+    assert not rgba.any()  # recording runs nothing
+    for _ in range(2):
+        rgb.zero_(); rgba.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(rgb, want_rgb) and torch.equal(rgba, want_rgba)
+    after = dev.stats()  # still the allocating call above
+    assert counts(after) == counts(want_st)
+    del graph
+    handle.release()
+
+
 def test_static_scratch_limits_are_reported(rtk, dev, device_mod):
     abi = rtk.abi
     # more spheres than the array has records for

@@ -65,7 +65,8 @@ struct Texture {
   uint32_t kind = RTK_TEX_SOLID;
   Color a = WHITE, b = BLACK;
   bool transformed = false;  // wrapped in a `TransformPattern` (src/graphics/patterns.rs:7-35)
-  Matrix4x4 transform = Matrix4x4::identity();
+  Matrix4x4 transform = Matrix4x4::identity();  // ... the outermost one's
+  std::vector<Matrix4x4> inner;                 // the transforms of the TransformPatterns inside it, outer to inner
   static Texture solid(Color c) { return make(RTK_TEX_SOLID, c, BLACK); }
   static Texture checker(Color a, Color b) { return make(RTK_TEX_CHECKER, a, b); }
   static Texture gradient(Color a, Color b) { return make(RTK_TEX_GRADIENT, a, b); }
@@ -76,6 +77,15 @@ struct Texture {
     Texture r = *this;
     r.transformed = true;
     r.transform = transform * t;
+    return r;
+  }
+  // `TransformPattern::new(self)`: one more wrapper, with the identity transform, around what is there
+  // (the type is generic over its pattern, so wrappers nest)
+  Texture wrap() const {
+    Texture r = *this;
+    if (transformed) r.inner.insert(r.inner.begin(), transform);
+    r.transformed = true;
+    r.transform = Matrix4x4::identity();
     return r;
   }
 
@@ -141,6 +151,7 @@ class Scene {
   struct Packed {
     std::vector<rtk_object> objects;
     std::vector<rtk_light> lights;
+    std::vector<std::vector<double>> inner_transforms;  // what rtk_material.inner_pattern_transforms points into
     rtk_scene scene;
   };
   void pack(Packed& storage) const;

@@ -65,6 +65,8 @@ Matrix4x4 Matrix4x4::operator*(const Matrix4x4& rhs) const {  // summation order
 void Scene::pack(Packed& st) const {
   st.objects.assign(nodes.size(), rtk_object{});
   st.lights.assign(lights.size(), rtk_light{});
+  st.inner_transforms.clear();
+  st.inner_transforms.reserve(nodes.size());  // the pointers handed out below must stay put
   for (size_t i = 0; i < nodes.size(); ++i) {
     const SceneNode& n = nodes[i];
     rtk_object& o = st.objects[i];
@@ -77,8 +79,15 @@ void Scene::pack(Packed& st) const {
     const Color a = n.material.texture.a, b = n.material.texture.b;
     m.color_a[0] = a.r, m.color_a[1] = a.g, m.color_a[2] = a.b;
     m.color_b[0] = b.r, m.color_b[1] = b.g, m.color_b[2] = b.b;
-    m.pattern_transformed = n.material.texture.transformed ? 1u : 0u;
-    std::memcpy(m.pattern_transform, n.material.texture.transform.e.data(), sizeof m.pattern_transform);
+    const Texture& tex = n.material.texture;
+    m.pattern_transformed = tex.transformed ? 1u + (uint32_t)tex.inner.size() : 0u;
+    std::memcpy(m.pattern_transform, tex.transform.e.data(), sizeof m.pattern_transform);
+    m.inner_pattern_transforms = nullptr;
+    if (tex.transformed && !tex.inner.empty()) {  // the struct points into storage the flattened scene keeps
+      st.inner_transforms.emplace_back();
+      for (const Matrix4x4& t : tex.inner) st.inner_transforms.back().insert(st.inner_transforms.back().end(), t.e.begin(), t.e.end());
+      m.inner_pattern_transforms = st.inner_transforms.back().data();
+    }
     m.ambient = n.material.ambient, m.diffuse = n.material.diffuse, m.specular = n.material.specular;
     m.shininess = n.material.shininess, m.transparency = n.material.transparency;
     m.reflectivity = n.material.reflectivity, m.refractivity = n.material.refractivity;

@@ -59,10 +59,15 @@ enum { RTK_TEX_SOLID = 0, RTK_TEX_CHECKER = 1, RTK_TEX_GRADIENT = 2, RTK_TEX_RIN
 #define RTK_TILE_H 8
 
 /* `Material` (src/scene/materials.rs:23-32).  For RTK_TEX_SOLID only color_a is used.
- * pattern_transformed != 0 wraps the pattern in a `TransformPattern`
- * (src/graphics/patterns.rs:7-35): the object-space point is multiplied by the inverse of
- * pattern_transform (row-major) before the pattern is sampled; a singular matrix leaves the
- * point as it is.  One level of wrapping; scene files cannot express it. */
+ * pattern_transformed = n > 0 wraps the pattern in n nested `TransformPattern`s
+ * (src/graphics/patterns.rs:7-35; the type is generic over its pattern, so a TransformPattern may
+ * wrap another): the object-space point is multiplied by the inverse of the OUTERMOST wrapper's
+ * transform first (pattern_transform, row-major), then by the inverses of the n - 1 inner ones in
+ * turn (inner_pattern_transforms: n - 1 matrices of 16 doubles, outer to inner; NULL for n <= 1),
+ * and the pattern is sampled at the result.  A wrapper whose matrix is singular leaves the point as
+ * it is, each on its own, as the reference's `if let Ok(inverse)` does.  The transforms need not be
+ * affine.  Scene files cannot express any of this.  At most RTK_MAX_PATTERN_LEVELS wrappers. */
+#define RTK_MAX_PATTERN_LEVELS 8
 typedef struct rtk_material {
   uint32_t texture_kind;
   uint32_t pattern_transformed;
@@ -71,6 +76,7 @@ typedef struct rtk_material {
   double ambient, diffuse, specular, shininess;
   double transparency, reflectivity, refractivity;
   double pattern_transform[16];
+  const double* inner_pattern_transforms;
 } rtk_material;
 
 /* `SceneNode<S>` (src/scene.rs:36-41).  The inverse transform is derived inside the
@@ -439,7 +445,8 @@ const char* rtk_version(void);
 /* The number of this header's struct layouts and entry points: it changes whenever a struct of
  * this header changes size or layout or an entry point changes meaning.  A host built against
  * this header compares it with RTK_ABI_VERSION before passing structs.  (2: rtk_stats has
- * gather_ms and RTK_ERR_RCCL exists; 3: rtk_group_info, shares and rows of a group.) */
+ * gather_ms and RTK_ERR_RCCL exists; 3: rtk_group_info, shares and rows of a group,
+ * rtk_material.inner_pattern_transforms.) */
 #define RTK_ABI_VERSION 3
 uint32_t rtk_abi_version(void);
 

@@ -242,9 +242,12 @@ inline Ray mul(const Mat4& m, const Ray& r) { return {mul(m, r.origin), mul(m, r
 // ------------------------------------------------------------------ patterns (src/graphics/patterns.rs)
 // Rust's `%` on f64 is C's fmod (sign of the dividend).
 inline Col sample_at(const rtk_material& m, Vec p) {  // src/scene/materials.rs:14-19
-  if (m.pattern_transformed) {  // `TransformPattern::sample_at` (src/graphics/patterns.rs:27-35): inverted per sample
+  // `TransformPattern::sample_at` (src/graphics/patterns.rs:27-35): inverted per sample; the type is generic
+  // over its pattern, so a TransformPattern may hold another: the outermost acts first, then each inner one
+  for (uint32_t level = 0; level < m.pattern_transformed; ++level) {
     Mat4 inverse;
-    if (invert(load16(m.pattern_transform), inverse)) p = mul(inverse, p);
+    if (invert(load16(level == 0 ? m.pattern_transform : m.inner_pattern_transforms + 16 * (size_t)(level - 1)), inverse))
+      p = mul(inverse, p);
   }
   Col a = load3(m.color_a), b = load3(m.color_b);
   switch (m.texture_kind) {

@@ -56,6 +56,7 @@ class rtk_material(C.Structure):
         ("reflectivity", C.c_double),
         ("refractivity", C.c_double),
         ("pattern_transform", Double16),
+        ("inner_pattern_transforms", C.POINTER(C.c_double)),
     ]
 
 
@@ -128,6 +129,7 @@ class rtk_banding(C.Structure):
     ]
 
 
+RTK_MAX_PATTERN_LEVELS = 8
 RTK_GROUP_INFO_MEMBERS = 16
 RTK_ABI_VERSION = 3
 

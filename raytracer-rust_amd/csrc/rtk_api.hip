@@ -274,6 +274,7 @@ int rtk::place_scene(rtk_context* ctx, const rtk::FlatScene& flat, rtk_scene_han
   d.plane_object = (decltype(d.plane_object))h->d_plane_object;
   d.plane_light = (decltype(d.plane_light))h->d_plane_light;
   d.pattern_inv = (decltype(d.pattern_inv))h->d_pattern_inv;
+  d.pattern_chain = (decltype(d.pattern_chain))h->d_pattern_chain;
   d.light_filter = (decltype(d.light_filter))h->d_light_filter;
   d.light_kind = (decltype(d.light_kind))h->d_light_kind;
   d.k_table = (decltype(d.k_table))h->d_k_table;
@@ -785,7 +786,9 @@ static int cached_scene(rtk_context* ctx, const rtk_scene* scene, rtk_scene_hand
   if ((scene->n_objects && !scene->objects) || (scene->n_lights && !scene->lights))
     return fail(RTK_ERR_INVALID, "rtk_scene_upload: null object or light array");
   const rtk_scene& c = ctx->cached_scene;
-  if (ctx->cached_handle && c.n_objects == scene->n_objects && c.n_lights == scene->n_lights && c.max_depth == scene->max_depth &&
+  // (a scene whose materials point to inner pattern transforms is never taken for the previous one:
+  // the comparison below sees the pointers, not what they point to)
+  if (ctx->cached_handle && !ctx->cached_has_pointers && c.n_objects == scene->n_objects && c.n_lights == scene->n_lights && c.max_depth == scene->max_depth &&
       std::memcmp(c.ambient_color, scene->ambient_color, sizeof c.ambient_color) == 0 &&
       (scene->n_objects == 0 ||
        std::memcmp(ctx->cached_objects.data(), scene->objects, (size_t)scene->n_objects * sizeof(rtk_object)) == 0) &&
@@ -837,6 +840,9 @@ static int cached_scene(rtk_context* ctx, const rtk_scene* scene, rtk_scene_hand
     return fail(RTK_ERR_NOMEM, "rtk_render: out of host memory");
   }
   ctx->cached_scene = *scene;
+  ctx->cached_has_pointers = false;
+  for (uint32_t i = 0; i < scene->n_objects && !ctx->cached_has_pointers; ++i)
+    ctx->cached_has_pointers = scene->objects[i].material.inner_pattern_transforms != nullptr;
   ctx->cached_handle = h;
   *out = h;
   return RTK_OK;

@@ -35,7 +35,7 @@ struct DevObject {
   double transparency, reflectivity, refractivity;
   double plane_normal[3];
   uint32_t kind;
-  uint32_t texture_kind;  // bit 31: the pattern has a transform of its own, see DevScene::pattern_inv
+  uint32_t texture_kind;  // bits 0-7: the kind; bit 31: the pattern has a transform of its own, see DevScene::pattern_inv; bits 8-11 / 12-30: length / first matrix of its chain in DevScene::pattern_chain when it is wrapped more than once
 };
 
 // What the exact test of one sphere needs, in sweep (cluster) order like the filter records, so
@@ -107,6 +107,7 @@ struct DevScene {
   const RTK_RO uint32_t* plane_object; // plane list -> object index
   const RTK_RO double2* plane_light;   // [plane][light]: row 1 of the plane's inverse applied to (L.xyz, L.w - 1), and 1e-12 x the sum of that row's term magnitudes (plane_may_block)
   const RTK_RO double* pattern_inv;    // per object, rows 0..2 of the inverse pattern transform (12 f64); null when no pattern has one
+  const RTK_RO double* pattern_chain;  // 16 f64 per matrix: the inverses, outer to inner, of patterns inside several TransformPatterns
   const RTK_RO float4* light_filter;   // per light: w = 0: unit line direction g = L/|L| and rho = -1/|L|; w = 1: position minus DevScene::center
   const RTK_RO uint32_t* light_kind;   // per light: 0 (w == 0), 1 (w == 1), 2 (anything else)
   const RTK_RO float4* k_table;        // [batch][sphere][k_width]: c_j.g_k - R_j'^2 rho_k, only when lights_uniform

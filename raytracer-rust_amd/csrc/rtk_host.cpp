@@ -530,13 +530,24 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   // Upper bound of the staged bytes (every piece rounded up to 256): the object array is built in
   // place at its start, the smaller arrays are copied behind it once their sizes are known.
   bool any_pattern = false;
-  for (uint32_t i = 0; i < scene->n_objects && !any_pattern; ++i) any_pattern = scene->objects[i].material.pattern_transformed != 0;
+  size_t chain_matrices = 0;  // of patterns wrapped more than once
+  for (uint32_t i = 0; i < scene->n_objects; ++i) {
+    const uint32_t levels = scene->objects[i].material.pattern_transformed;
+    any_pattern = any_pattern || levels != 0;
+    if (levels > RTK_MAX_PATTERN_LEVELS)
+      return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: more than RTK_MAX_PATTERN_LEVELS nested pattern transforms");
+    if (levels >= 2) {
+      if (!scene->objects[i].material.inner_pattern_transforms)
+        return fail(RTK_ERR_INVALID, "rtk_scene_upload: pattern_transformed > 1 without inner_pattern_transforms");
+      chain_matrices += levels;
+    }
+  }
   size_t n_planes_in = 0;
   for (uint32_t i = 0; i < scene->n_objects; ++i) n_planes_in += scene->objects[i].kind == RTK_PLANE;
   const size_t n_all = scene->n_objects, n_padded = n_all + kBundle, n_l = scene->n_lights;
   const size_t bound = 20 * 256 + n_planes_in * n_l * sizeof(double2) + n_all * sizeof(DevObject) + n_l * (sizeof(DevLight) + sizeof(float4) + sizeof(uint32_t)) +
                        n_padded * (3 * sizeof(float4) + sizeof(uint32_t) + sizeof(SphRecord)) + n_all * (sizeof(double4) + sizeof(uint32_t)) +
-                       (any_pattern ? n_all * 12 * sizeof(double) : 0) + ((n_l + 3) / 4) * n_padded * sizeof(float4) +
+                       (any_pattern ? n_all * 12 * sizeof(double) : 0) + chain_matrices * 16 * sizeof(double) + ((n_l + 3) / 4) * n_padded * sizeof(float4) +
                        2 * (n_padded / kBundle + kBundle) * sizeof(float4) + (n_padded / kBundle + kBundle) * sizeof(unsigned long long);
   if (flat.grow) {
     flat.staged = flat.grow(flat.user, bound);
@@ -547,7 +558,8 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   if (!flat.staged) return fail(RTK_ERR_NOMEM, "rtk_scene_upload: no staging memory");
   DevObject* const objects = reinterpret_cast<DevObject*>(flat.staged);
   std::vector<uint32_t> plane_object;
-  std::vector<double> pattern_inv;  // stays empty unless some pattern has a transform of its own
+  std::vector<double> pattern_inv;    // stays empty unless some pattern has a transform of its own
+  std::vector<double> pattern_chain;  // the inverses (16 doubles each, outer to inner) of patterns wrapped more than once
   bool track_n1 = false, any_secondary = false;
   float r2_max = 0.f, r_max = 0.f, c_max = 0.f;
 
@@ -596,7 +608,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
       std::memcpy(o.plane_normal, src.plane_normal, sizeof o.plane_normal);
       o.kind = src.kind;
       o.texture_kind = src.material.texture_kind;
-      if (src.material.pattern_transformed) {
+      if (src.material.pattern_transformed == 1u) {  // (nested wrappers: below, once the objects are done)
         // `TransformPattern` (src/graphics/patterns.rs:27-35): the reference inverts per sample and
         // samples the untransformed point when the matrix is singular
         M4 pinv;
@@ -621,6 +633,37 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
     if (oc.status != RTK_OK) return fail(oc.status, oc.message);
     track_n1 = track_n1 || oc.track_n1;
     any_secondary = any_secondary || oc.any_secondary;
+  }
+  // Patterns inside several TransformPatterns (the type nests, src/graphics/patterns.rs:7-35): every
+  // wrapper multiplies the point by its own inverse, the outermost first, and one whose matrix is
+  // singular leaves the point as it is -- so the singular ones drop out of the chain here.  One
+  // wrapper left: the per-object record of the single-wrapper case.  Several: their full inverses (the
+  // transforms need not be affine, so w travels along the chain) go to pattern_chain, and the object
+  // carries the chain's length (bits 8-11 of texture_kind) and its first matrix (bits 12-30).
+  if (chain_matrices) {
+    for (uint32_t i = 0; i < scene->n_objects; ++i) {
+      const rtk_material& mat = scene->objects[i].material;
+      if (mat.pattern_transformed < 2u) continue;
+      std::vector<M4> chain;
+      for (uint32_t k = 0; k < mat.pattern_transformed; ++k) {
+        M4 pinv;
+        if (m4_invert(m4_load(k == 0 ? mat.pattern_transform : mat.inner_pattern_transforms + 16 * (size_t)(k - 1)), pinv))
+          chain.push_back(pinv);
+      }
+      if (chain.empty()) continue;
+      DevObject& o = objects[i];
+      o.texture_kind |= 0x80000000u;
+      if (chain.size() == 1) {
+        // alone, a wrapper sees the object-space point (w = 1): rows 0..2 of its inverse are all it takes
+        std::memcpy(&pattern_inv[12 * (size_t)i], chain[0].e, 12 * sizeof(double));
+        continue;
+      }
+      const size_t first = pattern_chain.size() / 16;
+      if (first + chain.size() > (1u << 19))
+        return fail(RTK_ERR_UNSUPPORTED, "rtk_scene_upload: more than 524,288 nested pattern transforms in one scene");
+      o.texture_kind |= ((uint32_t)chain.size() << 8) | ((uint32_t)first << 12);
+      for (const M4& m : chain) pattern_chain.insert(pattern_chain.end(), m.e, m.e + 16);
+    }
   }
   // spheres (with the bounding balls of their images) and planes, in object order
   std::vector<SphereKey> keys;
@@ -703,6 +746,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   const size_t at_plane_object = reserve(&rtk_scene_handle::d_plane_object, plane_object.size() * sizeof(uint32_t));
   const size_t at_plane_light = reserve(&rtk_scene_handle::d_plane_light, plane_object.size() * scene->n_lights * sizeof(double2));
   const size_t at_pattern_inv = reserve(&rtk_scene_handle::d_pattern_inv, pattern_inv.size() * sizeof(double));
+  const size_t at_pattern_chain = reserve(&rtk_scene_handle::d_pattern_chain, pattern_chain.size() * sizeof(double));
   const size_t at_light_filter = reserve(&rtk_scene_handle::d_light_filter, (size_t)scene->n_lights * sizeof(float4));
   const size_t at_light_kind = reserve(&rtk_scene_handle::d_light_kind, (size_t)scene->n_lights * sizeof(uint32_t));
   const size_t at_k_table = reserve(&rtk_scene_handle::d_k_table, tabulated ? (size_t)batches * n_pad * k_width * sizeof(float) : 0);
@@ -748,6 +792,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   unsigned long long* const cluster_plain = reinterpret_cast<unsigned long long*>(base + at_cluster_plain);
   if (!plane_object.empty()) std::memcpy(base + at_plane_object, plane_object.data(), plane_object.size() * sizeof(uint32_t));
   if (!pattern_inv.empty()) std::memcpy(base + at_pattern_inv, pattern_inv.data(), pattern_inv.size() * sizeof(double));
+  if (!pattern_chain.empty()) std::memcpy(base + at_pattern_chain, pattern_chain.data(), pattern_chain.size() * sizeof(double));
 
   for (uint32_t k = 0; k < scene->n_lights; ++k) {
     std::memcpy(lights[k].pos, scene->lights[k].position, sizeof lights[k].pos);

@@ -34,6 +34,7 @@ struct rtk_scene_handle {
   void* d_plane_light = nullptr;
   void* d_light_kind = nullptr;
   void* d_pattern_inv = nullptr;
+  void* d_pattern_chain = nullptr;
   void* d_prim = nullptr;          // camera-ray filter records (rebuilt per camera)
   void* d_prim_ball = nullptr;     // camera-ray records of the wavefront-level cone test (rebuilt per camera)
   void* d_sph_ball = nullptr;

@@ -58,6 +58,7 @@ struct rtk_context {
   std::vector<rtk_light> cached_lights;
   rtk_scene cached_scene{};
   rtk_scene_handle* cached_handle = nullptr;
+  bool cached_has_pointers = false;  // some material of it points to inner pattern transforms
   // sample frame of rtk_render_device_sampled (grown on demand)
   float* d_samples = nullptr;
   size_t cap_samples = 0;  // in samples

@@ -298,8 +298,25 @@ __device__ __forceinline__ V3 sample_texture(const RTK_RO DevObject& ob, V3 p) {
 // object-space point (w = 1) goes through the inverse pattern transform first.  The inverse
 // is formed once at scene upload with the reference's cofactor method; a singular transform
 // is stored as "no transform".
+// A pattern inside several TransformPatterns: every wrapper's inverse in turn, outermost first, as
+// full 4x4 products (src/maths/vectors.rs:205-223) -- the transforms need not be affine, so w travels.
 __device__ __forceinline__ V3 sample_texture_at(const DevScene& S, const RTK_RO DevObject& ob, uint32_t obj, V3 objp) {
-  if (ob.texture_kind & 0x80000000u) objp = xform(S.pattern_inv + 12 * (size_t)obj, objp, 1.0);
+  const uint32_t tk = ob.texture_kind;
+  if (tk & 0x80000000u) {
+    const uint32_t levels = (tk >> 8) & 0xfu;
+    if (levels == 0u) {
+      objp = xform(S.pattern_inv + 12 * (size_t)obj, objp, 1.0);
+    } else {
+      double w = 1.0;
+      const RTK_RO double* m = S.pattern_chain + 16 * (size_t)((tk >> 12) & 0x7ffffu);
+      for (uint32_t k = 0; k < levels; ++k, m += 16) {
+        const V3 p = objp;
+        objp = {m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3] * w, m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7] * w,
+                m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11] * w};
+        w = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15] * w;
+      }
+    }
+  }
   return sample_texture(ob, objp);
 }
 

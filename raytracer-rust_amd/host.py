@@ -149,17 +149,27 @@ class Texture:
     """`Texture::{Solid, Pattern}` with the four patterns a scene file can name
     (src/scene/materials.rs:7-10, src/loader.rs:137-175)."""
 
-    __slots__ = ("kind", "a", "b", "transform")
+    __slots__ = ("kind", "a", "b", "transform", "inner")
 
-    def __init__(self, kind, a, b=BLACK, transform=None):
+    def __init__(self, kind, a, b=BLACK, transform=None, inner=()):
         self.kind, self.a, self.b = kind, rgb(*a), rgb(*b)
-        self.transform = transform  # None, or the Matrix4x4 of a `TransformPattern`
+        self.transform = transform  # None, or the Matrix4x4 of the outermost `TransformPattern`
+        self.inner = tuple(inner)   # the transforms of the TransformPatterns inside it, outer to inner
 
     def with_transform(self, transform):
         """`TransformPattern::new(pattern).with_transform(t)` (src/graphics/patterns.rs:12-25):
-        repeated calls multiply on the right."""
+        repeated calls multiply on the right.  Acts on the outermost wrapper."""
         current = self.transform if self.transform is not None else Matrix4x4.identity()
-        return Texture(self.kind, self.a, self.b, current * transform)
+        return Texture(self.kind, self.a, self.b, current * transform, self.inner)
+
+    def wrap(self):
+        """`TransformPattern::new(self)`: one more wrapper around what is there, with the identity
+        transform (the type is generic over its pattern, src/graphics/patterns.rs:7-35, so wrappers nest)."""
+        if self.transform is None:
+            return Texture(self.kind, self.a, self.b, Matrix4x4.identity(), self.inner)
+        if 1 + len(self.inner) >= abi.RTK_MAX_PATTERN_LEVELS:
+            raise ValueError(f"at most {abi.RTK_MAX_PATTERN_LEVELS} nested TransformPatterns")
+        return Texture(self.kind, self.a, self.b, Matrix4x4.identity(), (self.transform,) + self.inner)
 
     @staticmethod
     def solid(color):
@@ -235,8 +245,13 @@ class Material:
         m.color_a[:] = self.texture.a
         m.color_b[:] = self.texture.b
         if self.texture.transform is not None:
-            m.pattern_transformed = 1
+            m.pattern_transformed = 1 + len(self.texture.inner)
             m.pattern_transform[:] = self.texture.transform.e
+            if self.texture.inner:
+                flat = [v for t in self.texture.inner for v in t.e]
+                arr = (C.c_double * len(flat))(*flat)
+                m.inner_pattern_transforms = C.cast(arr, C.POINTER(C.c_double))
+                m._keep = arr  # the struct only holds a pointer
         m.ambient, m.diffuse, m.specular, m.shininess = self.ambient, self.diffuse, self.specular, self.shininess
         m.transparency, m.reflectivity, m.refractivity = self.transparency, self.reflectivity, self.refractivity
         return m
@@ -281,7 +296,9 @@ class SceneNode:
         o.kind = self.kind
         o.transform[:] = self.transform.e
         o.plane_normal[:] = self.plane_normal
-        o.material = self.material.to_abi()
+        m = self.material.to_abi()
+        o.material = m
+        o._keep = getattr(m, "_keep", None)  # inner pattern transforms the material points to
         return o
 
 
@@ -318,8 +335,12 @@ class Scene:
     def to_abi(self):
         """Flat rtk_scene; the arrays stay alive as attributes of the returned struct."""
         objs = (abi.rtk_object * max(1, len(self.nodes)))()
+        kept = []
         for i, n in enumerate(self.nodes):
-            objs[i] = n.to_abi()
+            o = n.to_abi()
+            objs[i] = o
+            if o._keep is not None:
+                kept.append(o._keep)
         lights = (abi.rtk_light * max(1, len(self.lights)))()
         for i, l in enumerate(self.lights):
             lights[i] = l.to_abi()
@@ -330,7 +351,7 @@ class Scene:
         s.n_lights = len(self.lights)
         s.ambient_color[:] = self.ambient_color
         s.max_depth = self.max_depth
-        s._keep = (objs, lights)
+        s._keep = (objs, lights, kept)
         return s
 
 

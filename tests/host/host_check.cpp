@@ -57,6 +57,10 @@ bool load_scene(const char* path, LoadedScene& out) {
   }
   std::fclose(f);
   if (!ok) return false;
+  for (rtk_object& o : out.objects) {  // a pointer of the process that wrote the file means nothing here
+    if (o.material.pattern_transformed > 1u) return false;
+    o.material.inner_pattern_transforms = nullptr;
+  }
   out.scene.objects = out.objects.data();
   out.scene.n_objects = h.n_objects;
   out.scene.lights = out.lights.data();
@@ -116,6 +120,27 @@ void argument_checks() {
   s.objects = &flat_o;
   uint64_t singular = 0;
   CHECK(rtk_flatten_digest(&s, &singular, nullptr) == RTK_OK && singular != 0);
+  // nested pattern transforms: the count needs its matrices, and has a limit
+  {
+    rtk_object nested = unit_sphere();
+    nested.material.texture_kind = RTK_TEX_CHECKER;
+    nested.material.pattern_transformed = 3;
+    for (int i = 0; i < 4; ++i) nested.material.pattern_transform[5 * i] = 1.0;
+    s.objects = &nested;
+    CHECK(rtk_flatten_digest(&s, &digest, &bytes) == RTK_ERR_INVALID);
+    double inner[2 * 16] = {};
+    for (int k = 0; k < 2; ++k)
+      for (int i = 0; i < 4; ++i) inner[16 * k + 5 * i] = 2.0 + k;
+    nested.material.inner_pattern_transforms = inner;
+    uint64_t with_chain = 0;
+    CHECK(rtk_flatten_digest(&s, &with_chain, &bytes) == RTK_OK);
+    inner[16 + 5] = 0.0;  // the innermost wrapper singular: a chain of two is left
+    uint64_t shorter = 0;
+    CHECK(rtk_flatten_digest(&s, &shorter, &bytes) == RTK_OK && shorter != with_chain);
+    nested.material.pattern_transformed = RTK_MAX_PATTERN_LEVELS + 1;
+    CHECK(rtk_flatten_digest(&s, &digest, &bytes) == RTK_ERR_UNSUPPORTED);
+    s.objects = &o;
+  }
   // an empty scene is a scene
   rtk_scene empty{};
   empty.max_depth = RTK_REFERENCE_MAX_DEPTH;

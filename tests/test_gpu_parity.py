@@ -503,6 +503,40 @@ def test_transformed_patterns(rtk, dev, oracle):
         check_against_oracle(dev, oracle, scene, rtk.Camera(480, 270, rtk.PI / 3), f"transformed patterns, reflective={reflective}")
 
 
+def test_nested_transformed_patterns(rtk, dev, oracle):
+    """TransformPatterns inside TransformPatterns (the type is generic over its pattern, src/graphics/patterns.rs:7-35):
+    every wrapper's inverse in turn, outermost first; singular wrappers drop out one by one; a wrapper need not be
+    affine (w then travels down the chain).  Opaque (fused kernel) and with a reflective floor (single kernel)."""
+    M = rtk.Matrix4x4
+    mat = rtk.Material.default()
+    T = rtk.Texture
+    projective = M(list(M.scale(0.4, 0.4, 0.4).e[:12]) + [0.05, 0.0, 0.1, 1.0])
+    for reflective in (0.0, 0.5):
+        scene = rtk.Scene()
+        scene.add_light(rtk.PointLight(rtk.vec3(-10, 10, -10), rtk.rgb(0.8, 0.8, 0.8)))
+        scene.add_light(rtk.PointLight(rtk.vec3(6, 12, -3), rtk.rgb(0.3, 0.3, 0.3)))
+        scene.add_object(rtk.Plane().with_material(mat.with_reflective(reflective).with_pattern(
+            T.checker(rtk.WHITE, rtk.rgb(0.1, 0.1, 0.1)).with_transform(M.scale(0.37, 0.37, 0.37)).wrap().with_transform(M.rotate_y(0.5))
+            .wrap().with_transform(M.translate(0.21, 0, -0.4)))))
+        scene.add_object(rtk.Sphere().with_transform(M.translate(-1.6, 1, 0.5)).with_material(mat.with_pattern(
+            T.striped(rtk.rgb(1, 0.2, 0.2), rtk.rgb(0.2, 0.2, 1)).with_transform(M.scale(0.2, 0.2, 0.2)).wrap().with_transform(M.rotate_z(0.7)))))
+        # a singular wrapper between two regular ones, and one at each end
+        scene.add_object(rtk.Sphere().with_transform(M.translate(0.6, 1, 0) * M.scale(1, 0.6, 1)).with_material(mat.with_pattern(
+            T.gradient(rtk.rgb(0, 1, 0), rtk.rgb(1, 0, 1)).with_transform(M.shear(0.5, 0, 0, 0, 0.2, 0)).wrap().with_transform(M.scale(1, 0, 1))
+            .wrap().with_transform(M.translate(0.3, 0, 0)))))
+        scene.add_object(rtk.Sphere().with_transform(M.translate(2.4, 0.7, -0.8) * M.scale(0.7, 0.7, 0.7)).with_material(mat.with_pattern(
+            T.ring(rtk.rgb(1, 1, 0), rtk.rgb(0, 0.3, 0.3)).with_transform(M.scale(0, 1, 1)).wrap().with_transform(M.scale(0.15, 1, 0.15))
+            .wrap().with_transform(M.scale(1, 1, 0)))))
+        # all wrappers singular: the pattern sees the object-space point
+        scene.add_object(rtk.Sphere().with_transform(M.translate(-0.4, 0.4, -1.6) * M.scale(0.4, 0.4, 0.4)).with_material(mat.with_pattern(
+            T.striped(rtk.WHITE, rtk.BLACK).with_transform(M.scale(0, 1, 1)).wrap().with_transform(M.scale(1, 1, 0)))))
+        # a wrapper that is not affine: its inverse changes w, which the next wrapper's translation then scales
+        scene.add_object(rtk.Sphere().with_transform(M.translate(1.2, 0.5, -2.0) * M.scale(0.5, 0.5, 0.5)).with_material(mat.with_pattern(
+            T.checker(rtk.rgb(0.9, 0.5, 0.1), rtk.rgb(0.1, 0.5, 0.9)).with_transform(M.translate(0.3, 0.2, 0.1) * M.scale(0.5, 0.5, 0.5))
+            .wrap().with_transform(projective))))
+        check_against_oracle(dev, oracle, scene, rtk.Camera(480, 270, rtk.PI / 3), f"nested patterns, reflective={reflective}")
+
+
 def test_large_scene_with_secondary_rays(rtk, dev, oracle):
     """400 and 1000 spheres, a quarter of them glass, reflective floor: reflected and refracted
     rays leave a wavefront in all directions, so opened clusters are swept sphere-per-lane."""

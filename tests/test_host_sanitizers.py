@@ -26,6 +26,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def dump_scene(rtk, scene, path):
     s = scene.to_abi()
+    # the file holds the structs as they lie in memory: no pointers inside them may be in use
+    assert all(s.objects[i].material.pattern_transformed <= 1 for i in range(s.n_objects))
     with open(path, "wb") as f:
         f.write(b"RTKS" + struct.pack("<III", s.n_objects, s.n_lights, s.max_depth) + struct.pack("<3d", *s.ambient_color))
         f.write(C.string_at(s.objects, s.n_objects * C.sizeof(rtk.abi.rtk_object)) if s.n_objects else b"")

@@ -408,3 +408,37 @@ def test_transform_pattern_scales_translates_and_ignores_singular(rtk, oracle):
     grad = rtk.Texture.gradient(rtk.rgb(0, 0, 0), rtk.rgb(1, 1, 1)).with_transform(M.rotate_y(rtk.PI / 2))
     got = sample(grad, rtk.point(0, 0, -0.25))   # inverse rotation takes z = -0.25 to x = 0.25
     assert all(abs(c - 0.25) < 1e-12 for c in got)
+
+
+def test_nested_transform_patterns_apply_outermost_first(rtk, oracle):
+    """`TransformPattern<P>` is generic over its pattern (src/graphics/patterns.rs:7-35), so one may hold another:
+    `sample_at` of the outer one multiplies the point by ITS inverse and hands it to the inner one, which does the
+    same.  The reference's tests hold no known answer for this (parity unpinned); the cases below are read off by
+    hand and tell the two possible orders apart."""
+    M = rtk.Matrix4x4
+    stripes = rtk.Texture.striped(rtk.WHITE, rtk.BLACK)
+
+    def sample(texture, p):
+        return tuple(oracle.texture_sample_at(rtk.Material.default().with_pattern(texture), p))
+
+    # inner: scale by 2; outer: translate by 1.  Outer first: (3.5 - 1) / 2 = 1.25 -> BLACK;
+    # the other order would give 3.5 / 2 - 1 = 0.75 -> WHITE
+    nested = stripes.with_transform(M.scale(2, 2, 2)).wrap().with_transform(M.translate(1, 0, 0))
+    assert nested.transform == M.translate(1, 0, 0) and nested.inner == (M.scale(2, 2, 2),)
+    assert sample(nested, rtk.point(3.5, 0, 0)) == rtk.BLACK
+    assert sample(nested, rtk.point(2.5, 0, 0)) == rtk.WHITE     # (2.5 - 1) / 2 = 0.75
+    # a wrapper with the identity changes nothing; a singular wrapper leaves the point to the next one
+    assert sample(nested.wrap(), rtk.point(3.5, 0, 0)) == rtk.BLACK
+    skipped = stripes.with_transform(M.scale(2, 2, 2)).wrap().with_transform(M.scale(0, 1, 1))
+    assert sample(skipped, rtk.point(3.5, 0, 0)) == rtk.BLACK    # 3.5 / 2 = 1.75
+    skipped_inner = stripes.with_transform(M.scale(0, 1, 1)).wrap().with_transform(M.translate(1, 0, 0))
+    assert sample(skipped_inner, rtk.point(2.5, 0, 0)) == rtk.BLACK   # 2.5 - 1 = 1.5
+    # three deep: translate 1, then scale 2, then translate 0.5: ((4.5 - 1) / 2) - 0.5 = 1.25
+    three = stripes.with_transform(M.translate(0.5, 0, 0)).wrap().with_transform(M.scale(2, 2, 2)).wrap().with_transform(M.translate(1, 0, 0))
+    assert len(three.inner) == 2 and sample(three, rtk.point(4.5, 0, 0)) == rtk.BLACK
+    assert sample(three, rtk.point(4.0, 0, 0)) == rtk.BLACK      # 1.0 -> floor 1
+    assert sample(three, rtk.point(3.9, 0, 0)) == rtk.WHITE      # 0.95
+    with pytest.raises(ValueError):
+        t = stripes
+        for _ in range(rtk.abi.RTK_MAX_PATTERN_LEVELS + 1):
+            t = t.wrap().with_transform(M.translate(1, 0, 0))

@@ -29,7 +29,7 @@ def test_header_and_binding_agree_on_the_symbol_list(rtk, lib):
 
 def test_struct_sizes_match_the_header_layout(rtk):
     a = rtk.abi
-    assert C.sizeof(a.rtk_material) == 8 + 6 * 8 + 7 * 8 + 16 * 8
+    assert C.sizeof(a.rtk_material) == 8 + 6 * 8 + 7 * 8 + 16 * 8 + 8  # the last 8: inner_pattern_transforms
     assert C.sizeof(a.rtk_object) == 8 + 16 * 8 + 4 * 8 + C.sizeof(a.rtk_material)
     assert C.sizeof(a.rtk_light) == 7 * 8
     assert C.sizeof(a.rtk_scene) == 8 + 8 + 8 + 8 + 24 + 8

@@ -107,6 +107,8 @@ def test_static_call_allocates_no_device_memory(rtk, dev, device_mod):
         outs.append((c, torch.zeros((c.height, c.width, 3), dtype=torch.float32, device=dev.tdev),
                      torch.zeros((c.height, c.width, 4), dtype=torch.uint8, device=dev.tdev)))
     stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):  # the runtime sets up a stream's hardware queue at the first launch on it
+        torch.zeros(64, device=dev.tdev).add_(1.0)
     torch.cuda.synchronize()
     free_before = torch.cuda.mem_get_info()[0]
     for c, rgb, rgba in outs:

@@ -71,6 +71,8 @@ for name, counters in sorted(agg.items()):
         d["issue_stall_share"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
     if "SQ_WAVES" in m and "SQ_INSTS_VALU" in m:
         d["valu_per_wave"] = m["SQ_INSTS_VALU"] / m["SQ_WAVES"]
+    if "SQ_WAVES" in m and "SQ_INSTS_SALU" in m:
+        d["salu_per_wave"] = m["SQ_INSTS_SALU"] / m["SQ_WAVES"]
     out[name] = d
     print(name)
     for k, v in d.items():
@@ -105,7 +107,8 @@ if "--measured" in sys.argv:
         "f32_flops_per_launch": d.get("f32_flops_per_launch"),
         "wait_any_share": d.get("wait_any_share"),
         "issue_stall_share": d.get("issue_stall_share"),
-        "valu_per_wave": d.get("valu_per_wave"),
+        "valu_per_wavefront": d.get("valu_per_wave"),
+        "salu_per_wavefront": d.get("salu_per_wave"),
         "avg_waves_per_simd": d.get("avg_waves_per_simd"),
         "clock_GHz": d.get("clock_GHz"),
         "source": src,

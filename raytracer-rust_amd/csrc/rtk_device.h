@@ -119,6 +119,12 @@ struct DevScene {
   const RTK_RO LightGrid* light_grid;  // per light, when shadow_grid
   const RTK_RO uint2* grid_cells;      // {first entry, entries} per cell, the lights' grids one after the other
   const RTK_RO uint32_t* grid_entries; // sweep positions of spheres
+  // The cell grid walked by rays with a direction of their own, when trace_grid: cubic cells of side
+  // 1 / tg_inv_h from the corner tg_lo (world coordinates), tg_n cells per axis, x fastest; a cell lists
+  // the spheres whose bounding ball (plus a margin) reaches into it: entries first .. first + count - 1.
+  const RTK_RO uint2* tg_cells;        // {first entry, entries} per cell
+  const RTK_RO float4* tg_filter;      // per entry: the sphere's sph_filter record
+  const RTK_RO uint32_t* tg_slot;      // per entry: the sphere's sweep position
   uint32_t n_objects, n_lights, n_spheres, n_spheres_padded, n_planes;
   uint32_t n_clusters_padded;
   uint32_t n_spheres_grouped;  // n_spheres rounded up to kGroup: what the one-ray-per-lane sweeps cover
@@ -129,6 +135,9 @@ struct DevScene {
   uint32_t lights_bundled; // every light has w == 0 or w == 1: the shadow rays of a patch form lines / cones
   uint32_t k_width;        // lights per k_table row (4 or 8)
   uint32_t shadow_grid;    // the light grids exist (lights_uniform scenes with secondary rays and a cluster hierarchy)
+  uint32_t trace_grid;     // the cell grid exists
+  uint32_t tg_n[3];
+  double tg_lo[3], tg_inv_h;
   double center[3];      // recentring offset of the FP32 filter
   double ambient[3];
   float r2_max;          // max inflated squared radius

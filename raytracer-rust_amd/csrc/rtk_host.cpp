@@ -520,6 +520,126 @@ static bool build_light_grids(const SphereKey* keys, uint32_t n_sph, const doubl
   return true;
 }
 
+// The FP32 filter record of a sphere: its centre relative to `center`, rounded, and a squared radius
+// that covers the rounding (and a relative 1e-9 for the exact test's own rounding).
+static float4 filter_record(const SphereKey& key, const double* center) {
+  const double cd[3] = {key.c[0] - center[0], key.c[1] - center[1], key.c[2] - center[2]};
+  const float cf[3] = {(float)cd[0], (float)cd[1], (float)cd[2]};
+  const double dx = cd[0] - cf[0], dy = cd[1] - cf[1], dz = cd[2] - cf[2];
+  const double shift = std::sqrt(dx * dx + dy * dy + dz * dz);  // actual displacement of the rounded centre
+  const double R = key.r * (1.0 + 1e-9) + shift * 1.0001;
+  return make_float4(cf[0], cf[1], cf[2], round_up(R * R));
+}
+
+// The cell grid that rays with a direction of their own (reflected and refracted rays) walk cell by
+// cell (trace-grid fields of DevScene): cubic cells over the box around all bounding balls, each cell
+// listing the spheres whose ball, grown by a margin, reaches into it.  The margin (3 % of a cell plus
+// 1e-5 of the box's size) is what lets the device walk the cells in FP32 and stop at the first cell
+// that begins behind the closest hit: a point of the ray is never further from a visited cell, and a
+// computed root never further from the ball, than a small part of it.  keys: the spheres in sweep
+// order (list entries are sweep positions).  False when the lists would be long (spheres much larger
+// than the cells that many small ones ask for): the scene keeps the cluster sweeps.
+struct TraceGridBuild {
+  double lo[3] = {0, 0, 0}, inv_h = 0.0;
+  uint32_t n[3] = {0, 0, 0};
+  std::vector<uint2> cells;
+  std::vector<float4> filter;  // per list entry: the sphere's filter record ...
+  std::vector<uint32_t> slot;  // ... and its sweep position
+};
+static bool build_trace_grid(const SphereKey* keys, uint32_t n_sph, const double* center, TraceGridBuild& out) {
+  if (n_sph == 0) return false;
+  struct Ball {
+    double c[3], r;
+  };
+  std::vector<Ball> balls(n_sph);
+  double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX}, r_sum = 0.0;
+  for (uint32_t j = 0; j < n_sph; ++j) {
+    const float4 f = filter_record(keys[j], center);
+    Ball& b = balls[j];
+    b.c[0] = center[0] + (double)f.x, b.c[1] = center[1] + (double)f.y, b.c[2] = center[2] + (double)f.z;
+    b.r = std::sqrt((double)f.w);
+    r_sum += b.r;
+    for (int a = 0; a < 3; ++a) lo[a] = std::fmin(lo[a], b.c[a] - b.r), hi[a] = std::fmax(hi[a], b.c[a] + b.r);
+  }
+  double extent[3], e_max = 0.0, diag2 = 0.0;
+  for (int a = 0; a < 3; ++a) {
+    extent[a] = hi[a] - lo[a];
+    if (!std::isfinite(lo[a]) || !std::isfinite(hi[a]) || !(extent[a] >= 0.0)) return false;
+    e_max = std::fmax(e_max, extent[a]);
+    diag2 += extent[a] * extent[a];
+  }
+  if (!(e_max > 0.0) || !std::isfinite(diag2) || !std::isfinite(r_sum)) return false;
+  const double diag = std::sqrt(diag2);
+  constexpr uint32_t kAxisMax = 256u;
+  // cell size: about two cells per sphere, not below three quarters of the mean radius
+  auto cells_at = [&](double h) {
+    double c = 1.0;
+    for (int a = 0; a < 3; ++a) c *= std::fmax(1.0, std::ceil(extent[a] / h));
+    return c;
+  };
+  double h = e_max / kAxisMax;
+  while (cells_at(h) > 2.0 * n_sph) h *= 1.1;
+  h = std::fmax(h, 0.75 * r_sum / n_sph);
+  for (int attempt = 0; attempt < 5; ++attempt, h *= 1.6) {
+    const double pad = 0.01 * h;  // the box begins a little outside the balls
+    uint32_t n[3];
+    double g_lo[3];
+    for (int a = 0; a < 3; ++a) {
+      g_lo[a] = lo[a] - pad;
+      n[a] = (uint32_t)std::fmin((double)kAxisMax, std::fmax(1.0, std::ceil((extent[a] + 2.0 * pad) / h)));
+    }
+    // the last cell of an axis that was capped (or rounded) must still reach the far side
+    bool covers = true;
+    for (int a = 0; a < 3; ++a) covers = covers && g_lo[a] + n[a] * h >= hi[a] + 0.5 * pad;
+    if (!covers) continue;
+    const double inv_h = 1.0 / h, margin = 0.03 * h + 1e-5 * diag;
+    auto range = [&](const Ball& b, int a, uint32_t& i0, uint32_t& i1) {
+      const double a0 = (b.c[a] - b.r - margin - g_lo[a]) * inv_h, a1 = (b.c[a] + b.r + margin - g_lo[a]) * inv_h;
+      i0 = a0 <= 0.0 ? 0u : std::min<uint32_t>((uint32_t)a0, n[a] - 1u);
+      i1 = a1 <= 0.0 ? 0u : std::min<uint32_t>((uint32_t)a1, n[a] - 1u);
+    };
+    auto reaches = [&](const Ball& b, uint32_t x, uint32_t y, uint32_t z) {  // the grown ball and the cell's box
+      const uint32_t i[3] = {x, y, z};
+      double d2 = 0.0;
+      for (int a = 0; a < 3; ++a) {
+        const double c_lo = g_lo[a] + i[a] * h, c_hi = c_lo + h;
+        const double d = std::fmax(0.0, std::fmax(c_lo - b.c[a], b.c[a] - c_hi));
+        d2 += d * d;
+      }
+      const double reach = b.r + margin;
+      return d2 <= reach * reach * (1.0 + 1e-9);
+    };
+    out.cells.assign((size_t)n[0] * n[1] * n[2], make_uint2(0u, 0u));
+    auto each_cell = [&](uint32_t j, auto&& fn) {
+      uint32_t x0, x1, y0, y1, z0, z1;
+      range(balls[j], 0, x0, x1), range(balls[j], 1, y0, y1), range(balls[j], 2, z0, z1);
+      for (uint32_t z = z0; z <= z1; ++z)
+        for (uint32_t y = y0; y <= y1; ++y)
+          for (uint32_t x = x0; x <= x1; ++x)
+            if (reaches(balls[j], x, y, z)) fn(out.cells[((size_t)z * n[1] + y) * n[0] + x]);
+    };
+    size_t total = 0;
+    const size_t limit = (size_t)24u * n_sph + 64u;
+    for (uint32_t j = 0; j < n_sph && total <= limit; ++j) each_cell(j, [&](uint2& c) { ++c.y, ++total; });
+    if (total > limit) continue;  // long lists: try larger cells
+    uint32_t at = 0;
+    for (uint2& c : out.cells) c.x = at, at += c.y, c.y = 0;
+    out.filter.resize(total), out.slot.resize(total);
+    for (uint32_t j = 0; j < n_sph; ++j) {
+      const float4 f = filter_record(keys[j], center);
+      each_cell(j, [&](uint2& c) {
+        out.filter[c.x + c.y] = f;
+        out.slot[c.x + c.y] = j;
+        ++c.y;
+      });
+    }
+    for (int a = 0; a < 3; ++a) out.lo[a] = g_lo[a], out.n[a] = n[a];
+    out.inv_h = inv_h;
+    return true;
+  }
+  return false;
+}
+
 static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   if ((scene->n_objects && !scene->objects) || (scene->n_lights && !scene->lights))
     return fail(RTK_ERR_INVALID, "rtk_scene_upload: null object or light array");
@@ -725,6 +845,11 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   const bool shadow_grid = any_secondary && lights_uniform && n_sph >= 256u &&
                            build_light_grids(keys.data(), n_sph, center, gd, scene->n_lights, grids);
 
+  // the cell grid for rays with a direction of their own: where rays recurse and the spheres are too
+  // many to be intersected one by one
+  TraceGridBuild tgrid;
+  const bool trace_grid = any_secondary && scene->max_depth >= 2 && n_sph >= 32u && build_trace_grid(keys.data(), n_sph, center, tgrid);
+
   // One device allocation and one copy for all record arrays (each 256-byte aligned inside it):
   // the arrays are laid out first and then written where they will be copied from.  The
   // per-camera records, which only kernels write, follow at the end of the allocation.
@@ -759,16 +884,28 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   const size_t copied = total;
   // built apart from the staged bytes (their size is not known when the staging is sized), copied behind them
   const size_t extra_begin = total;
-  size_t at_light_grid = 0, at_grid_cells = 0, at_grid_entries = 0;
-  if (shadow_grid) {
-    at_light_grid = reserve(&rtk_scene_handle::d_light_grid, grids.header.size() * sizeof(rtk::LightGrid)) - extra_begin;
-    at_grid_cells = reserve(&rtk_scene_handle::d_grid_cells, grids.cells.size() * sizeof(uint2)) - extra_begin;
-    at_grid_entries = reserve(&rtk_scene_handle::d_grid_entries, grids.entries.size() * sizeof(uint32_t)) - extra_begin;
+  {
+    struct Extra {
+      size_t at;
+      const void* from;
+      size_t bytes;
+    };
+    std::vector<Extra> extras;
+    auto extra = [&](void* rtk_scene_handle::*dst, const void* from, size_t bytes) {
+      if (bytes) extras.push_back({reserve(dst, bytes) - extra_begin, from, bytes});
+    };
+    if (shadow_grid) {
+      extra(&rtk_scene_handle::d_light_grid, grids.header.data(), grids.header.size() * sizeof(rtk::LightGrid));
+      extra(&rtk_scene_handle::d_grid_cells, grids.cells.data(), grids.cells.size() * sizeof(uint2));
+      extra(&rtk_scene_handle::d_grid_entries, grids.entries.data(), grids.entries.size() * sizeof(uint32_t));
+    }
+    if (trace_grid) {
+      extra(&rtk_scene_handle::d_tg_cells, tgrid.cells.data(), tgrid.cells.size() * sizeof(uint2));
+      extra(&rtk_scene_handle::d_tg_filter, tgrid.filter.data(), tgrid.filter.size() * sizeof(float4));
+      extra(&rtk_scene_handle::d_tg_slot, tgrid.slot.data(), tgrid.slot.size() * sizeof(uint32_t));
+    }
     flat.extra.assign(total - extra_begin, 0);
-    std::memcpy(flat.extra.data() + at_light_grid, grids.header.data(), grids.header.size() * sizeof(rtk::LightGrid));
-    std::memcpy(flat.extra.data() + at_grid_cells, grids.cells.data(), grids.cells.size() * sizeof(uint2));
-    if (!grids.entries.empty())
-      std::memcpy(flat.extra.data() + at_grid_entries, grids.entries.data(), grids.entries.size() * sizeof(uint32_t));
+    for (const Extra& e : extras) std::memcpy(flat.extra.data() + e.at, e.from, e.bytes);
   }
   reserve(&rtk_scene_handle::d_prim, (size_t)n_pad * sizeof(float4));
   reserve(&rtk_scene_handle::d_prim_ball, (size_t)n_pad * sizeof(float4));
@@ -860,15 +997,10 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
         sph_exact[j] = make_double4(key.c[0], key.c[1], key.c[2], key.r);
         sph_object[j] = key.object;
         // FP32 filter record: the rounded centre, and a radius that covers the rounding
-        const double cd[3] = {key.c[0] - center[0], key.c[1] - center[1], key.c[2] - center[2]};
-        const float cf[3] = {(float)cd[0], (float)cd[1], (float)cd[2]};
-        const double dx = cd[0] - cf[0], dy = cd[1] - cf[1], dz = cd[2] - cf[2];
-        const double shift = std::sqrt(dx * dx + dy * dy + dz * dz);  // actual displacement of the rounded centre
-        const double R = key.r * (1.0 + 1e-9) + shift * 1.0001;
-        const float r2 = round_up(R * R);
-        filter[j] = make_float4(cf[0], cf[1], cf[2], r2);
+        filter[j] = filter_record(key, center);
+        const float cf[3] = {filter[j].x, filter[j].y, filter[j].z}, r2 = filter[j].w;
         mx.r2 = std::fmax(mx.r2, r2);
-        mx.r = std::fmax(mx.r, round_up(R));
+        mx.r = std::fmax(mx.r, round_up(std::sqrt((double)r2)));
         mx.c = std::fmax(mx.c, round_up(std::sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]) * 1.0001));
         exact_record(j, key.object);
         // record of the wavefront-level test: centre and (not squared) inflated radius
@@ -938,6 +1070,11 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   d.lights_bundled = lights_bundled ? 1u : 0u;
   d.k_width = k_width;
   d.shadow_grid = shadow_grid ? 1u : 0u;
+  d.trace_grid = trace_grid ? 1u : 0u;
+  if (trace_grid) {
+    for (int a = 0; a < 3; ++a) d.tg_lo[a] = tgrid.lo[a], d.tg_n[a] = tgrid.n[a];
+    d.tg_inv_h = tgrid.inv_h;
+  }
   d.n_objects = scene->n_objects;
   d.n_lights = scene->n_lights;
   d.n_spheres = n_sph;
@@ -1101,8 +1238,10 @@ uint64_t rtk::flat_scene_digest(const rtk::FlatScene& flat) {
   if (!flat.extra.empty()) bytes(flat.extra.data(), flat.extra.size());
   const rtk::DevScene& d = flat.dev;
   for (uint32_t v : {d.n_objects, d.n_lights, d.n_spheres, d.n_spheres_padded, d.n_planes, d.n_clusters_padded, d.n_spheres_grouped,
-                     d.max_depth, d.track_n1, d.any_secondary, d.lights_uniform, d.lights_bundled, d.k_width, d.shadow_grid})
+                     d.max_depth, d.track_n1, d.any_secondary, d.lights_uniform, d.lights_bundled, d.k_width, d.shadow_grid,
+                     d.trace_grid, d.tg_n[0], d.tg_n[1], d.tg_n[2]})
     word(v);
+  bytes(d.tg_lo, sizeof d.tg_lo), bytes(&d.tg_inv_h, sizeof d.tg_inv_h);
   bytes(d.center, sizeof d.center), bytes(d.ambient, sizeof d.ambient);
   bytes(&d.r2_max, sizeof d.r2_max), bytes(&d.r_max, sizeof d.r_max), bytes(&d.c_max, sizeof d.c_max);
   return h;

@@ -44,6 +44,9 @@ struct rtk_scene_handle {
   void* d_light_grid = nullptr;
   void* d_grid_cells = nullptr;
   void* d_grid_entries = nullptr;
+  void* d_tg_cells = nullptr;
+  void* d_tg_filter = nullptr;
+  void* d_tg_slot = nullptr;
   void* d_prim_cluster = nullptr;  // camera-ray records of the cluster balls (rebuilt per camera)
   void* d_light_filter = nullptr;
   void* d_k_table = nullptr;

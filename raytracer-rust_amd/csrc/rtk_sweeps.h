@@ -457,6 +457,200 @@ __device__ __forceinline__ void closest_general(const DevScene& S, bool active, 
   sweep_filter<1, WIDE>(S, live, (float)pc.x, (float)pc.y, (float)pc.z, gx, gy, gz, rho, thr, wc, exact, done, !track);
 }
 
+// ------------------------------------------------------------------------------------
+// The same for 64 rays that have nothing to do with each other (reflected and refracted rays queued
+// from all over the frame), through the scene's cell grid: every lane walks ITS ray from cell to cell
+// (a 3D DDA in cell units) and tests the spheres listed in each cell -- the per-ray FP32 filter, then
+// f64 on what it keeps.  A wavefront-wide cluster sweep opens every cluster that any of its 64 rays
+// comes near, which for unrelated rays is most of the scene; a walk looks at the few cells along one
+// ray and stops at the first cell that begins behind the closest hit found.
+//
+// What makes stopping sound.  Lists hold every sphere whose bounding ball, grown by a margin of 3 % of a
+// cell plus 1e-5 of the grid's size, reaches into the cell (rtk_scene_upload).  The walk starts from
+// a point of the ray computed in f64 and keeps positions in cell units (at most 256 per axis), so the
+// cells it visits differ from those of the exact ray only where the ray passes within about 1e-4 cells
+// of a cell boundary; and the f64 roots of a sphere far less than the margin away from its ball.  So a
+// sphere with a root in the stretch of the ray walked so far is listed in one of the cells visited,
+// and a walk may end once the current cell's far side lies 0.05 cells behind the best root.  Rays
+// that start further from the grid than 100 times its size, or whose direction has no usable length,
+// do not take the walk: the caller sweeps them.
+//
+// Lanes whose filter kept a sphere wait with it until 24 of them do, or until no lane has anything
+// else to do: the f64 test then runs for all of them at once instead of once per lane and candidate.
+// backward: the walk runs against the ray's direction and ends behind the largest root <= 0 (the
+// entry before the winner, whose material is n1).
+template <bool TRACK>
+__device__ __forceinline__ void grid_walk(const DevScene& S, bool active, V3 o, V3 d, bool backward, Closest& best,
+                                          WaveCount& wc, bool& graze) {
+  constexpr bool track = TRACK;
+  const double dd = dot3(d, d);
+  const double rs = __builtin_amdgcn_rsq(dd);  // relative error about 1e-8: the walk needs a direction, not the direction
+  const double sign = backward ? -1.0 : 1.0;
+  const double len_h = dd * rs * S.tg_inv_h;   // ray parameter -> cell units
+  const double oc[3] = {(o.x - S.tg_lo[0]) * S.tg_inv_h, (o.y - S.tg_lo[1]) * S.tg_inv_h, (o.z - S.tg_lo[2]) * S.tg_inv_h};
+  const double g[3] = {d.x * rs * sign, d.y * rs * sign, d.z * rs * sign};
+  // the stretch of the ray inside the grid's box, in cell units from the origin
+  double s_in = 0.0, s_out = 1.0e300;
+  bool alive = active;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double n = (double)S.tg_n[a];
+    if (fabs(g[a]) > 1.0e-9) {
+      const double r = __builtin_amdgcn_rcp(g[a]);
+      const double t0 = (0.0 - oc[a]) * r, t1 = (n - oc[a]) * r;
+      s_in = fmax(s_in, fmin(t0, t1));
+      s_out = fmin(s_out, fmax(t0, t1));
+    } else if (!(oc[a] >= 0.0 && oc[a] <= n)) {
+      alive = false;
+    }
+  }
+  s_in = fmax(s_in - 0.01, 0.0);  // the reciprocals above are approximate: begin a little early
+  alive = alive && s_in <= s_out + 0.01;
+  // first cell, position inside it, and the walk's constants
+  int ic[3], step[3];
+  float e[3], inv[3], far[3], t_next[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double ea = __builtin_fma(g[a], s_in, oc[a]);
+    const int n = (int)S.tg_n[a];
+    int i = (int)floor(ea);
+    i = i < 0 ? 0 : (i >= n ? n - 1 : i);  // (a NaN lands in cell 0 of a lane that is not alive)
+    ic[a] = i;
+    e[a] = (float)ea;
+    const float ga = (float)g[a];
+    const bool moves = fabsf(ga) > 1.0e-9f;
+    inv[a] = moves ? __builtin_amdgcn_rcpf(ga) : 0.0f;
+    far[a] = moves ? 0.0f : 3.0e38f;  // an axis the ray does not move along is never the next to be crossed
+    step[a] = ga > 0.0f ? 1 : -1;
+    t_next[a] = __builtin_fmaf((float)(i + (step[a] > 0 ? 1 : 0)) - e[a], inv[a], far[a]);
+  }
+  // the FP32 filter of this ray (sweep_filter's, with rho = 0)
+  float gx, gy, gz, rho_unused;
+  make_filter_ray(d, 0.0, gx, gy, gz, rho_unused);
+  const V3 pc = {o.x - S.center[0], o.y - S.center[1], o.z - S.center[2]};
+  const float px = (float)pc.x, py = (float)pc.y, pz = (float)pc.z;
+  const float thr = filter_threshold(S, pc, 0.0f);
+  // the best root so far in the walk's units (distance from the walk's first point, in cells)
+  auto best_at = [&]() -> float {
+    const double t = backward ? -best.prev_t : best.t;  // DBL_MAX without one: stays beyond every cell
+    return (float)fmin(__builtin_fma(t, len_h, -s_in), 1.0e30);
+  };
+  float best_u = best_at();
+  uint32_t e_cur = 0, e_end = 0, cand = 0, seen0 = 0xffffffffu, seen1 = 0xffffffffu;
+  bool pending = false;
+  int budget = (int)(S.tg_n[0] + S.tg_n[1] + S.tg_n[2]) + 4;  // cells a straight line can cross
+  auto fetch_list = [&]() {
+    const uint2 cell = S.tg_cells[((uint32_t)ic[2] * S.tg_n[1] + (uint32_t)ic[1]) * S.tg_n[0] + (uint32_t)ic[0]];
+    e_cur = cell.x, e_end = cell.x + cell.y;
+  };
+  if (alive) fetch_list();
+  for (;;) {
+    if (alive && !pending) {
+      if (e_cur < e_end) {
+        const float4 c = S.tg_filter[e_cur];
+        const float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
+        const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+        const float cf = __builtin_fmaf(uu, kKappa, -c.w);
+        const float h = __builtin_fmaf(uz, gz, __builtin_fmaf(uy, gy, ux * gx));
+        if (__builtin_fmaf(h, h, -cf) >= thr) {
+          const uint32_t slot = S.tg_slot[e_cur];
+          if (slot != seen0 && slot != seen1) {  // a ball lies in several cells: the last two tested are not tested again
+            seen1 = seen0, seen0 = slot;
+            cand = slot, pending = true;
+          }
+        }
+        ++e_cur;
+      } else {
+        // done with this cell: stop behind the best root, else cross into the next cell
+        const float u_exit = fminf(t_next[0], fminf(t_next[1], t_next[2]));
+        if (best_u < u_exit - 0.05f || --budget < 0) {
+          alive = false;
+        } else {
+          const int a = (t_next[0] <= t_next[1] && t_next[0] <= t_next[2]) ? 0 : (t_next[1] <= t_next[2] ? 1 : 2);
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (k == a) {
+              ic[k] += step[k];
+              t_next[k] = __builtin_fmaf((float)(ic[k] + (step[k] > 0 ? 1 : 0)) - e[k], inv[k], far[k]);
+              if (ic[k] < 0 || ic[k] >= (int)S.tg_n[k]) alive = false;
+            }
+          if (alive) fetch_list();
+        }
+      }
+    }
+    const unsigned long long waiting = __builtin_amdgcn_ballot_w64(pending);
+    const unsigned long long working = __builtin_amdgcn_ballot_w64(alive && !pending);
+    if (waiting != 0ull && (__builtin_popcountll(waiting) >= 24 || working == 0ull)) {
+      wc.exact += (unsigned)__builtin_popcountll(waiting);
+      if (pending) {
+        const RTK_RO SphRecord& rec = S.sph_record[cand];
+        double t0, t1;
+        if (intersect_sphere_record(S, rec, o, d, 0.0, t0, t1)) {
+          closest_consider(best, t0, rec.object, track);
+          closest_consider(best, t1, rec.object, track);
+          if (track && fabs(t0 - t1) < 0.00001) graze = true;  // `Hit::eq` would call the two roots one hit
+          best_u = best_at();
+        }
+        pending = false;
+      }
+    } else if (working == 0ull) {
+      break;  // nobody waits, nobody works
+    }
+  }
+}
+
+// May this lane's ray take the walk?  (Comparisons are written so that a NaN says no.)
+__device__ __forceinline__ bool grid_walk_applies(const DevScene& S, V3 o, V3 d) {
+  const double dd = dot3(d, d);
+  const double n_max = (double)max(S.tg_n[0], max(S.tg_n[1], S.tg_n[2]));
+  const double reach = 100.0 * n_max;
+  bool ok = dd > 1.0e-280 && dd < 1.0e280;
+  ok = ok && fabs((o.x - S.tg_lo[0]) * S.tg_inv_h) <= reach && fabs((o.y - S.tg_lo[1]) * S.tg_inv_h) <= reach &&
+       fabs((o.z - S.tg_lo[2]) * S.tg_inv_h) <= reach;
+  return ok;
+}
+
+// Closest hit of a ray with an origin and a direction of its own: the walk where the scene has a cell
+// grid and the ray may take it, the cluster sweep otherwise.
+template <bool WIDE, bool TRACK>
+__device__ __forceinline__ void closest_secondary(const DevScene& S, bool active, V3 o, V3 d, Closest& best, WaveCount& wc,
+                                                  bool& graze) {
+  if (!S.trace_grid) {
+    closest_general<WIDE, TRACK>(S, active, o, d, best, wc, graze);
+    return;
+  }
+  constexpr bool track = TRACK;
+  closest_init(best);
+  const bool walks = active && grid_walk_applies(S, o, d);
+  if (walks) {
+    for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
+      const uint32_t obj = S.plane_object[ip];
+      double t0, t1;
+      if (intersect_object(S.objects[obj], o, d, 0.0, t0, t1)) closest_consider(best, t0, obj, track);
+    }
+  }
+  // forward for the winner; then, where the winner's material asks for n1, backward for the entry before it
+#pragma unroll 1
+  for (int pass = 0; pass < (TRACK ? 2 : 1); ++pass) {
+    bool go = walks;
+    if (pass == 1) {
+      go = walks && best.obj != 0xffffffffu;
+      if (go) {
+        const RTK_RO DevObject& ob = S.objects[best.obj];
+        go = !is_approx_zero(ob.reflectivity) || !is_approx_zero(ob.transparency);
+      }
+    }
+    if (__any(go)) grid_walk<TRACK>(S, go, o, d, pass == 1, best, wc, graze);
+  }
+  const bool swept = active && !walks;
+  if (__any(swept)) {
+    Closest other;
+    bool other_graze = false;
+    closest_general<WIDE, TRACK>(S, swept, o, d, other, wc, other_graze);
+    if (swept) best = other, graze = other_graze;
+  }
+}
+
 // Closest hit of a camera ray (unit direction, shared origin).
 template <bool TRACK>
 __device__ __forceinline__ void closest_primary(const DevScene& S, const float4* __restrict__ prim,

@@ -187,7 +187,7 @@ __device__ __forceinline__ void trace_step(const DevScene& S, const float4* __re
   else if (PRIMARY_FILTER && camera_sweep)
     closest_primary<TRACK>(S, prim, prim_cluster, have, ro, rd, best, wc, graze);
   else
-    closest_general<WIDE, TRACK>(S, have, ro, rd, best, wc, graze);
+    closest_secondary<WIDE, TRACK>(S, have, ro, rd, best, wc, graze);
 
   const bool hit = have && best.obj != 0xffffffffu;
   if (have && !hit) sink.term(scene_ambient, weight);  // trace_inner: miss -> ambient_color

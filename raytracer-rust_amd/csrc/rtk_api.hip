@@ -286,6 +286,7 @@ int rtk::place_scene(rtk_context* ctx, const rtk::FlatScene& flat, rtk_scene_han
   d.light_grid = (decltype(d.light_grid))h->d_light_grid;
   d.grid_cells = (decltype(d.grid_cells))h->d_grid_cells;
   d.grid_entries = (decltype(d.grid_entries))h->d_grid_entries;
+  d.grid_filter = (decltype(d.grid_filter))h->d_grid_filter;
   d.tg_cells = (decltype(d.tg_cells))h->d_tg_cells;
   d.tg_filter = (decltype(d.tg_filter))h->d_tg_filter;
   d.tg_slot = (decltype(d.tg_slot))h->d_tg_slot;

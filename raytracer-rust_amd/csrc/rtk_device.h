@@ -119,6 +119,7 @@ struct DevScene {
   const RTK_RO LightGrid* light_grid;  // per light, when shadow_grid
   const RTK_RO uint2* grid_cells;      // {first entry, entries} per cell, the lights' grids one after the other
   const RTK_RO uint32_t* grid_entries; // sweep positions of spheres
+  const RTK_RO float4* grid_filter;    // ... and, entry by entry, their sph_filter records
   // The cell grid walked by rays with a direction of their own, when trace_grid: cubic cells of side
   // 1 / tg_inv_h from the corner tg_lo (world coordinates), tg_n cells per axis, x fastest; a cell lists
   // the spheres whose bounding ball (plus a margin) reaches into it: entries first .. first + count - 1.

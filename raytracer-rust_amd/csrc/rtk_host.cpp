@@ -381,6 +381,17 @@ int rtk::flatten_scene(const rtk_scene* scene, rtk::FlatScene& out) {
   }
 }
 
+// The FP32 filter record of a sphere: its centre relative to `center`, rounded, and a squared radius
+// that covers the rounding (and a relative 1e-9 for the exact test's own rounding).
+static float4 filter_record(const SphereKey& key, const double* center) {
+  const double cd[3] = {key.c[0] - center[0], key.c[1] - center[1], key.c[2] - center[2]};
+  const float cf[3] = {(float)cd[0], (float)cd[1], (float)cd[2]};
+  const double dx = cd[0] - cf[0], dy = cd[1] - cf[1], dz = cd[2] - cf[2];
+  const double shift = std::sqrt(dx * dx + dy * dy + dz * dz);  // actual displacement of the rounded centre
+  const double R = key.r * (1.0 + 1e-9) + shift * 1.0001;
+  return make_float4(cf[0], cf[1], cf[2], round_up(R * R));
+}
+
 // The light grids of a scene whose lights all have w = 0 (LightGrid in rtk_device.h), one per light,
 // built side by side on the library's host threads.  keys: the spheres in sweep order; gd: per light the unit
 // direction and rho = -1/|L|.  False when a grid would not pay (lists too long, too many lights):
@@ -388,7 +399,8 @@ int rtk::flatten_scene(const rtk_scene* scene, rtk::FlatScene& out) {
 struct LightGrids {
   std::vector<rtk::LightGrid> header;
   std::vector<uint2> cells;
-  std::vector<uint32_t> entries;
+  std::vector<uint32_t> entries;  // sweep positions ...
+  std::vector<float4> filter;     // ... and filter records of the listed spheres
 };
 static bool build_light_grids(const SphereKey* keys, uint32_t n_sph, const double* center, const std::vector<double>& gd,
                               uint32_t n_lights, LightGrids& out) {
@@ -398,14 +410,12 @@ static bool build_light_grids(const SphereKey* keys, uint32_t n_sph, const doubl
     double c[3], r;
   };
   std::vector<Disc> discs(n_sph);
+  std::vector<float4> records(n_sph);
   double scale = 0.0;
   for (uint32_t j = 0; j < n_sph; ++j) {
-    const double cd[3] = {keys[j].c[0] - center[0], keys[j].c[1] - center[1], keys[j].c[2] - center[2]};
-    const float cf[3] = {(float)cd[0], (float)cd[1], (float)cd[2]};
-    const double dx = cd[0] - cf[0], dy = cd[1] - cf[1], dz = cd[2] - cf[2];
-    const double R = keys[j].r * (1.0 + 1e-9) + std::sqrt(dx * dx + dy * dy + dz * dz) * 1.0001;
-    discs[j] = {{(double)cf[0], (double)cf[1], (double)cf[2]}, std::sqrt((double)round_up(R * R))};
-    scale = std::fmax(scale, std::sqrt((double)cf[0] * cf[0] + (double)cf[1] * cf[1] + (double)cf[2] * cf[2]) + discs[j].r);
+    const float4 f = records[j] = filter_record(keys[j], center);
+    discs[j] = {{(double)f.x, (double)f.y, (double)f.z}, std::sqrt((double)f.w)};
+    scale = std::fmax(scale, std::sqrt((double)f.x * f.x + (double)f.y * f.y + (double)f.z * f.z) + discs[j].r);
   }
   struct PerLight {
     rtk::LightGrid header{};
@@ -507,7 +517,7 @@ static bool build_light_grids(const SphereKey* keys, uint32_t n_sph, const doubl
       per[k].ok = false;
     }
   });
-  out.header.clear(), out.cells.clear(), out.entries.clear();
+  out.header.clear(), out.cells.clear(), out.entries.clear(), out.filter.clear();
   for (PerLight& pl : per) {
     if (!pl.ok) return false;
     pl.header.cell_base = (uint32_t)out.cells.size();
@@ -517,18 +527,9 @@ static bool build_light_grids(const SphereKey* keys, uint32_t n_sph, const doubl
     out.cells.insert(out.cells.end(), pl.cells.begin(), pl.cells.end());
     out.entries.insert(out.entries.end(), pl.entries.begin(), pl.entries.end());
   }
+  out.filter.resize(out.entries.size());
+  for (size_t i = 0; i < out.entries.size(); ++i) out.filter[i] = records[out.entries[i]];
   return true;
-}
-
-// The FP32 filter record of a sphere: its centre relative to `center`, rounded, and a squared radius
-// that covers the rounding (and a relative 1e-9 for the exact test's own rounding).
-static float4 filter_record(const SphereKey& key, const double* center) {
-  const double cd[3] = {key.c[0] - center[0], key.c[1] - center[1], key.c[2] - center[2]};
-  const float cf[3] = {(float)cd[0], (float)cd[1], (float)cd[2]};
-  const double dx = cd[0] - cf[0], dy = cd[1] - cf[1], dz = cd[2] - cf[2];
-  const double shift = std::sqrt(dx * dx + dy * dy + dz * dz);  // actual displacement of the rounded centre
-  const double R = key.r * (1.0 + 1e-9) + shift * 1.0001;
-  return make_float4(cf[0], cf[1], cf[2], round_up(R * R));
 }
 
 // The cell grid that rays with a direction of their own (reflected and refracted rays) walk cell by
@@ -898,6 +899,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
       extra(&rtk_scene_handle::d_light_grid, grids.header.data(), grids.header.size() * sizeof(rtk::LightGrid));
       extra(&rtk_scene_handle::d_grid_cells, grids.cells.data(), grids.cells.size() * sizeof(uint2));
       extra(&rtk_scene_handle::d_grid_entries, grids.entries.data(), grids.entries.size() * sizeof(uint32_t));
+      extra(&rtk_scene_handle::d_grid_filter, grids.filter.data(), grids.filter.size() * sizeof(float4));
     }
     if (trace_grid) {
       extra(&rtk_scene_handle::d_tg_cells, tgrid.cells.data(), tgrid.cells.size() * sizeof(uint2));

@@ -44,6 +44,7 @@ struct rtk_scene_handle {
   void* d_light_grid = nullptr;
   void* d_grid_cells = nullptr;
   void* d_grid_entries = nullptr;
+  void* d_grid_filter = nullptr;
   void* d_tg_cells = nullptr;
   void* d_tg_filter = nullptr;
   void* d_tg_slot = nullptr;

@@ -383,29 +383,38 @@ __device__ __forceinline__ bool shadow_by_grids(const DevScene& S, bool active, 
         first = c.x, count = c.y;
       }
     }
-    for (uint32_t base = 0; __any(base < count); base += 64u) {
-      // the per-ray filter over up to 64 listed spheres, then f64 on those it keeps
-      const uint32_t here = base < count ? min(count - base, 64u) : 0u;
-      unsigned long long kept = 0ull;
-      for (uint32_t e = 0; __any(e < here); ++e) {
-        if (e < here) {
-          const float4 c = S.sph_filter[S.grid_entries[first + base + e]];
-          const float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
+    // the listed spheres four at a time (their filter records lie side by side in the list, so the four
+    // loads are in flight together): the per-ray filter, then f64 on those it keeps
+    for (uint32_t base = 0; __any(base < count); base += 4u) {
+      uint32_t kept = 0u, slot[4] = {0u, 0u, 0u, 0u};
+      if (base < count) {
+        const uint32_t here = min(count - base, 4u);
+        float4 c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t e = first + base + min((uint32_t)i, here - 1u);  // a short batch repeats its last entry
+          c[i] = S.grid_filter[e];
+          slot[i] = S.grid_entries[e];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float ux = px - c[i].x, uy = py - c[i].y, uz = pz - c[i].z;
           const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-          const float cf = __builtin_fmaf(uu, kKappa, -c.w);
-          const float h = __builtin_fmaf(uz, lf.z, __builtin_fmaf(uy, lf.y, __builtin_fmaf(ux, lf.x, c.w * lf.w)));
-          if (__builtin_fmaf(h, h, -cf) >= thr) kept |= 1ull << e;
+          const float cf = __builtin_fmaf(uu, kKappa, -c[i].w);
+          const float h = __builtin_fmaf(uz, lf.z, __builtin_fmaf(uy, lf.y, __builtin_fmaf(ux, lf.x, c[i].w * lf.w)));
+          if ((uint32_t)i < here && __builtin_fmaf(h, h, -cf) >= thr) kept |= 1u << i;
         }
       }
-      while (__any(kept != 0ull)) {
-        wc.exact += lanes_where(kept != 0ull);
-        if (kept != 0ull) {
-          const uint32_t e = (uint32_t)__builtin_ctzll(kept);
-          kept &= kept - 1ull;
-          const RTK_RO SphRecord& rec = S.sph_record[S.grid_entries[first + base + e]];
+      while (__any(kept != 0u)) {
+        wc.exact += lanes_where(kept != 0u);
+        if (kept != 0u) {
+          const uint32_t i = (uint32_t)__builtin_ctz(kept);
+          kept &= kept - 1u;
+          const uint32_t at = i == 0u ? slot[0] : (i == 1u ? slot[1] : (i == 2u ? slot[2] : slot[3]));
+          const RTK_RO SphRecord& rec = S.sph_record[at];
           double t0, t1;
           const int n = intersect_sphere_record(S, rec, p, d, dw, t0, t1);
-          if (n == 2 && ((t0 > 0.0 && t0 < m) || (t1 > 0.0 && t1 < m))) blocked = true, kept = 0ull, count = 0u;
+          if (n == 2 && ((t0 > 0.0 && t0 < m) || (t1 > 0.0 && t1 < m))) blocked = true, kept = 0u, count = 0u;
         }
       }
     }
@@ -536,30 +545,36 @@ __device__ __forceinline__ void grid_walk(const DevScene& S, bool active, V3 o, 
     return (float)fmin(__builtin_fma(t, len_h, -s_in), 1.0e30);
   };
   float best_u = best_at();
-  uint32_t e_cur = 0, e_end = 0, cand = 0, seen0 = 0xffffffffu, seen1 = 0xffffffffu;
-  bool pending = false;
+  uint32_t first = 0, count = 0, base = 0;  // the current cell's list, and how much of it is done
+  uint32_t kept = 0u, slot[4] = {0u, 0u, 0u, 0u}, seen0 = 0xffffffffu, seen1 = 0xffffffffu;
   int budget = (int)(S.tg_n[0] + S.tg_n[1] + S.tg_n[2]) + 4;  // cells a straight line can cross
   auto fetch_list = [&]() {
     const uint2 cell = S.tg_cells[((uint32_t)ic[2] * S.tg_n[1] + (uint32_t)ic[1]) * S.tg_n[0] + (uint32_t)ic[0]];
-    e_cur = cell.x, e_end = cell.x + cell.y;
+    first = cell.x, count = cell.y, base = 0u;
   };
   if (alive) fetch_list();
   for (;;) {
-    if (alive && !pending) {
-      if (e_cur < e_end) {
-        const float4 c = S.tg_filter[e_cur];
-        const float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
-        const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-        const float cf = __builtin_fmaf(uu, kKappa, -c.w);
-        const float h = __builtin_fmaf(uz, gz, __builtin_fmaf(uy, gy, ux * gx));
-        if (__builtin_fmaf(h, h, -cf) >= thr) {
-          const uint32_t slot = S.tg_slot[e_cur];
-          if (slot != seen0 && slot != seen1) {  // a ball lies in several cells: the last two tested are not tested again
-            seen1 = seen0, seen0 = slot;
-            cand = slot, pending = true;
-          }
+    if (alive && kept == 0u) {
+      if (base < count) {
+        // four entries of the list at a time: their loads are in flight together
+        const uint32_t here = min(count - base, 4u);
+        float4 c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t en = first + base + min((uint32_t)i, here - 1u);  // a short batch repeats its last entry
+          c[i] = S.tg_filter[en];
+          slot[i] = S.tg_slot[en];
         }
-        ++e_cur;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float ux = px - c[i].x, uy = py - c[i].y, uz = pz - c[i].z;
+          const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+          const float cf = __builtin_fmaf(uu, kKappa, -c[i].w);
+          const float h = __builtin_fmaf(uz, gz, __builtin_fmaf(uy, gy, ux * gx));
+          // a ball lies in several cells: the last two spheres tested are not tested again
+          if ((uint32_t)i < here && __builtin_fmaf(h, h, -cf) >= thr && slot[i] != seen0 && slot[i] != seen1) kept |= 1u << i;
+        }
+        base += 4u;
       } else {
         // done with this cell: stop behind the best root, else cross into the next cell
         const float u_exit = fminf(t_next[0], fminf(t_next[1], t_next[2]));
@@ -578,12 +593,16 @@ __device__ __forceinline__ void grid_walk(const DevScene& S, bool active, V3 o, 
         }
       }
     }
-    const unsigned long long waiting = __builtin_amdgcn_ballot_w64(pending);
-    const unsigned long long working = __builtin_amdgcn_ballot_w64(alive && !pending);
+    const unsigned long long waiting = __builtin_amdgcn_ballot_w64(kept != 0u);
+    const unsigned long long working = __builtin_amdgcn_ballot_w64(alive && kept == 0u);
     if (waiting != 0ull && (__builtin_popcountll(waiting) >= 24 || working == 0ull)) {
       wc.exact += (unsigned)__builtin_popcountll(waiting);
-      if (pending) {
-        const RTK_RO SphRecord& rec = S.sph_record[cand];
+      if (kept != 0u) {
+        const uint32_t i = (uint32_t)__builtin_ctz(kept);
+        kept &= kept - 1u;
+        const uint32_t at = i == 0u ? slot[0] : (i == 1u ? slot[1] : (i == 2u ? slot[2] : slot[3]));
+        seen1 = seen0, seen0 = at;
+        const RTK_RO SphRecord& rec = S.sph_record[at];
         double t0, t1;
         if (intersect_sphere_record(S, rec, o, d, 0.0, t0, t1)) {
           closest_consider(best, t0, rec.object, track);
@@ -591,7 +610,6 @@ __device__ __forceinline__ void grid_walk(const DevScene& S, bool active, V3 o, 
           if (track && fabs(t0 - t1) < 0.00001) graze = true;  // `Hit::eq` would call the two roots one hit
           best_u = best_at();
         }
-        pending = false;
       }
     } else if (working == 0ull) {
       break;  // nobody waits, nobody works

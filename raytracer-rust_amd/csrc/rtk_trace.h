@@ -220,13 +220,19 @@ __device__ __forceinline__ void trace_step(const DevScene& S, const float4* __re
     }
   }
 
+#if defined(RTK_NODE_CUT) && RTK_NODE_CUT >= 1  // experiment builds (wrong images): a node without its shadow rays
+  const bool in_shadow = false;
+#else
   const bool in_shadow = BRUTE ? shadow_brute(S, hit, over, wc) : shadow_sweeps<LB, WIDE>(S, hit, over, wc);
+#endif
 
   if (hit) {
     const RTK_RO DevObject& ob = S.objects[obj];
     V3 surface = scene_ambient;
+#if !defined(RTK_NODE_CUT) || RTK_NODE_CUT < 2  // ... and without its lights
     for (uint32_t k = 0; k < S.n_lights; ++k)
       surface = surface + phong_lighting(S.lights[k], ob, tex, over, eye, normal, in_shadow);
+#endif
     sink.term(surface, weight);
   }
 }

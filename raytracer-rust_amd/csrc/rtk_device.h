@@ -97,6 +97,16 @@ struct LightGrid {
 };
 static_assert(sizeof(LightGrid) == 64, "one light grid header is 64 bytes");
 
+// One cell of the grid that rays with a direction of their own walk: where its list lies, how long it
+// is, and the first two entries of the list themselves -- most lists are no longer, and a lane that
+// enters the cell then has all it needs after one round trip to memory.
+struct TraceCell {
+  uint32_t first, count;  // entries first .. first + count - 1 of DevScene::tg_filter / tg_slot
+  uint32_t slot[2];       // sweep positions of the first two (unused ones: 0)
+  float4 filter[2];       // ... and their filter records
+};
+static_assert(sizeof(TraceCell) == 48, "a cell record is three 16-byte loads");
+
 struct DevScene {
   const RTK_RO DevObject* objects;
   const RTK_RO DevLight* lights;
@@ -123,7 +133,7 @@ struct DevScene {
   // The cell grid walked by rays with a direction of their own, when trace_grid: cubic cells of side
   // 1 / tg_inv_h from the corner tg_lo (world coordinates), tg_n cells per axis, x fastest; a cell lists
   // the spheres whose bounding ball (plus a margin) reaches into it: entries first .. first + count - 1.
-  const RTK_RO uint2* tg_cells;        // {first entry, entries} per cell
+  const RTK_RO TraceCell* tg_cells;    // per cell: its list's place and length, and the list's first two entries
   const RTK_RO float4* tg_filter;      // per entry: the sphere's sph_filter record
   const RTK_RO uint32_t* tg_slot;      // per entry: the sphere's sweep position
   uint32_t n_objects, n_lights, n_spheres, n_spheres_padded, n_planes;

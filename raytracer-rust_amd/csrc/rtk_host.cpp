@@ -424,8 +424,9 @@ static bool build_light_grids(const SphereKey* keys, uint32_t n_sph, const doubl
     bool ok = false;
   };
   std::vector<PerLight> per(n_lights);
-  auto build = [&](uint32_t k) {
+  auto build = [&](uint32_t k, bool deep) {
     PerLight& pl = per[k];
+    pl = PerLight{};
     const double g[3] = {gd[4 * k], gd[4 * k + 1], gd[4 * k + 2]}, arho = std::fabs(gd[4 * k + 3]);
     // basis of the plane perpendicular to g
     int a = 0;
@@ -438,9 +439,19 @@ static bool build_light_grids(const SphereKey* keys, uint32_t n_sph, const doubl
     for (double& v : e1) v /= n1;
     const double e2[3] = {g[1] * e1[2] - g[2] * e1[1], g[2] * e1[0] - g[0] * e1[2], g[0] * e1[1] - g[1] * e1[0]};
     const float e1f[3] = {(float)e1[0], (float)e1[1], (float)e1[2]}, e2f[3] = {(float)e2[0], (float)e2[1], (float)e2[2]};
-    // every shading point on a sphere lies at or above the lowest point of the lowest sphere
+    // every shading point on a sphere lies at or above the lowest point of the lowest sphere; the floor
+    // is lowered to the lowest corner of the box around the spheres (deep == true), so that points of a
+    // plane underneath or between the spheres are in range as well
     double h_min = DBL_MAX;
     for (const Disc& d : discs) h_min = std::fmin(h_min, d.c[0] * g[0] + d.c[1] * g[1] + d.c[2] * g[2] - d.r);
+    if (deep) {
+      double b_lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, b_hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+      for (const Disc& d : discs)
+        for (int i = 0; i < 3; ++i) b_lo[i] = std::fmin(b_lo[i], d.c[i] - d.r), b_hi[i] = std::fmax(b_hi[i], d.c[i] + d.r);
+      double h_corner = 0.0;
+      for (int i = 0; i < 3; ++i) h_corner += std::fmin(b_lo[i] * g[i], b_hi[i] * g[i]);
+      h_min = std::fmin(h_min, h_corner);
+    }
     const double margin = 1e-4 * (1.0 + scale);
     h_min -= 2.0 * margin;
     // a sphere's shadow at height h has radius^2 = R^2 (1 + R^2 rho^2 + 2 |rho| (c.g - h)): widest at h_min
@@ -512,7 +523,8 @@ static bool build_light_grids(const SphereKey* keys, uint32_t n_sph, const doubl
   };
   HostPool::get().run(n_lights, [&](uint32_t k) {
     try {
-      build(k);
+      build(k, true);
+      if (!per[k].ok) build(k, false);  // lists too long with the lower floor: the spheres' own floor
     } catch (const std::bad_alloc&) {
       per[k].ok = false;
     }
@@ -546,6 +558,7 @@ struct TraceGridBuild {
   std::vector<uint2> cells;
   std::vector<float4> filter;  // per list entry: the sphere's filter record ...
   std::vector<uint32_t> slot;  // ... and its sweep position
+  std::vector<rtk::TraceCell> records;  // the cells as the device reads them
 };
 static bool build_trace_grid(const SphereKey* keys, uint32_t n_sph, const double* center, TraceGridBuild& out) {
   if (n_sph == 0) return false;
@@ -633,6 +646,15 @@ static bool build_trace_grid(const SphereKey* keys, uint32_t n_sph, const double
         out.slot[c.x + c.y] = j;
         ++c.y;
       });
+    }
+    out.records.assign(out.cells.size(), rtk::TraceCell{});
+    for (size_t c = 0; c < out.cells.size(); ++c) {
+      rtk::TraceCell& r = out.records[c];
+      r.first = out.cells[c].x, r.count = out.cells[c].y;
+      for (uint32_t k = 0; k < 2u; ++k) {
+        r.slot[k] = k < r.count ? out.slot[r.first + k] : 0u;
+        r.filter[k] = k < r.count ? out.filter[r.first + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     for (int a = 0; a < 3; ++a) out.lo[a] = g_lo[a], out.n[a] = n[a];
     out.inv_h = inv_h;
@@ -902,7 +924,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
       extra(&rtk_scene_handle::d_grid_filter, grids.filter.data(), grids.filter.size() * sizeof(float4));
     }
     if (trace_grid) {
-      extra(&rtk_scene_handle::d_tg_cells, tgrid.cells.data(), tgrid.cells.size() * sizeof(uint2));
+      extra(&rtk_scene_handle::d_tg_cells, tgrid.records.data(), tgrid.records.size() * sizeof(rtk::TraceCell));
       extra(&rtk_scene_handle::d_tg_filter, tgrid.filter.data(), tgrid.filter.size() * sizeof(float4));
       extra(&rtk_scene_handle::d_tg_slot, tgrid.slot.data(), tgrid.slot.size() * sizeof(uint32_t));
     }

@@ -14,8 +14,8 @@ constexpr uint32_t kHasTerm = 1u, kUntracedRefraction = 2u, kUntracedReflection 
 // words of the control block
 constexpr int kCtrlNodes = 0;     // nodes handed out so far in this pass (camera rays included)
 constexpr int kCtrlOverflow = 1;  // some child found no room: the launch is to be rendered again
-constexpr int kCtrlClaim = 2;     // next node of the current level no wavefront has taken yet
-constexpr int kCtrlLevelEnd = 3;  // [kCtrlLevelEnd + l]: one past the last node of level l
+constexpr int kCtrlLevelEnd = 3;  // [kCtrlLevelEnd + l]: one past the last node of level l (l <= kMaxDepth)
+static_assert(kCtrlLevelEnd + kMaxDepth < (int)kWavefrontCtrlWords, "one level end per depth fits the control block");
 
 // Result sink for one node of the level-by-level order: keeps the node's terms and queues its
 // children.  The workgroups of these kernels move in step (one node per lane, then all together): a

@@ -342,8 +342,17 @@ __device__ __forceinline__ bool shadow_by_grids(const DevScene& S, bool active, 
     in_range = in_range && h >= S.light_grid[k].h_min;
     rho_max = fmaxf(rho_max, fabsf(lf.w) * 1.0001f);
   }
+#if defined(RTK_SHADOW_CUT) && RTK_SHADOW_CUT == 1  // experiment builds (wrong images): no point takes the cluster sweeps
+  in_range = active;
+#endif
+#if defined(RTK_SHADOW_CUT) && RTK_SHADOW_CUT == 2  // ... no point looks at a grid's lists
+  in_range = false;
+  const bool swept = false;
+  bool in_shadow = false;
+#else
   bool in_shadow = false;
   const bool swept = active && !in_range;
+#endif
   if (__any(swept)) {
     const bool s = shadow_by_sweeps<LB, WIDE>(S, swept, p, wc);
     if (swept) in_shadow = s;
@@ -548,15 +557,36 @@ __device__ __forceinline__ void grid_walk(const DevScene& S, bool active, V3 o, 
   uint32_t first = 0, count = 0, base = 0;  // the current cell's list, and how much of it is done
   uint32_t kept = 0u, slot[4] = {0u, 0u, 0u, 0u}, seen0 = 0xffffffffu, seen1 = 0xffffffffu;
   int budget = (int)(S.tg_n[0] + S.tg_n[1] + S.tg_n[2]) + 4;  // cells a straight line can cross
-  auto fetch_list = [&]() {
-    const uint2 cell = S.tg_cells[((uint32_t)ic[2] * S.tg_n[1] + (uint32_t)ic[1]) * S.tg_n[0] + (uint32_t)ic[0]];
-    first = cell.x, count = cell.y, base = 0u;
+  // the filter of one entry: does the ray come near the sphere?  (a ball lies in several cells: the last
+  // two spheres tested are not tested again)
+  auto keeps = [&](const float4 c, uint32_t at) {
+    const float ux = px - c.x, uy = py - c.y, uz = pz - c.z;
+    const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+    const float cf = __builtin_fmaf(uu, kKappa, -c.w);
+    const float h = __builtin_fmaf(uz, gz, __builtin_fmaf(uy, gy, ux * gx));
+    return __builtin_fmaf(h, h, -cf) >= thr && at != seen0 && at != seen1;
   };
-  if (alive) fetch_list();
+  // entering a cell: its record brings the first two entries of its list along
+  auto enter_cell = [&]() {
+    const RTK_RO TraceCell& cell = S.tg_cells[((uint32_t)ic[2] * S.tg_n[1] + (uint32_t)ic[1]) * S.tg_n[0] + (uint32_t)ic[0]];
+    first = cell.first, count = cell.count, base = 2u;
+    slot[0] = cell.slot[0], slot[1] = cell.slot[1];
+    const float4 c0 = cell.filter[0], c1 = cell.filter[1];
+    if (count >= 1u && keeps(c0, slot[0])) kept |= 1u;
+    if (count >= 2u && keeps(c1, slot[1])) kept |= 2u;
+  };
+#if defined(RTK_HIT_CUT) && RTK_HIT_CUT == 1  // experiment builds (wrong images): no walk at all
+  alive = false;
+#endif
+#if defined(RTK_HIT_CUT) && RTK_HIT_CUT == 2  // ... only the first cell
+  budget = 0;
+#endif
+  if (alive) enter_cell();
+  [[maybe_unused]] int stat_rounds = 0;
   for (;;) {
     if (alive && kept == 0u) {
       if (base < count) {
-        // four entries of the list at a time: their loads are in flight together
+        // the rest of a longer list, four entries at a time: their loads are in flight together
         const uint32_t here = min(count - base, 4u);
         float4 c[4];
 #pragma unroll
@@ -566,14 +596,8 @@ __device__ __forceinline__ void grid_walk(const DevScene& S, bool active, V3 o, 
           slot[i] = S.tg_slot[en];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float ux = px - c[i].x, uy = py - c[i].y, uz = pz - c[i].z;
-          const float uu = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-          const float cf = __builtin_fmaf(uu, kKappa, -c[i].w);
-          const float h = __builtin_fmaf(uz, gz, __builtin_fmaf(uy, gy, ux * gx));
-          // a ball lies in several cells: the last two spheres tested are not tested again
-          if ((uint32_t)i < here && __builtin_fmaf(h, h, -cf) >= thr && slot[i] != seen0 && slot[i] != seen1) kept |= 1u << i;
-        }
+        for (int i = 0; i < 4; ++i)
+          if ((uint32_t)i < here && keeps(c[i], slot[i])) kept |= 1u << i;
         base += 4u;
       } else {
         // done with this cell: stop behind the best root, else cross into the next cell
@@ -589,14 +613,22 @@ __device__ __forceinline__ void grid_walk(const DevScene& S, bool active, V3 o, 
               t_next[k] = __builtin_fmaf((float)(ic[k] + (step[k] > 0 ? 1 : 0)) - e[k], inv[k], far[k]);
               if (ic[k] < 0 || ic[k] >= (int)S.tg_n[k]) alive = false;
             }
-          if (alive) fetch_list();
+          if (alive) enter_cell();
         }
       }
     }
     const unsigned long long waiting = __builtin_amdgcn_ballot_w64(kept != 0u);
     const unsigned long long working = __builtin_amdgcn_ballot_w64(alive && kept == 0u);
+#if defined(RTK_WALK_STATS)  // experiment builds: exact_tests counts something else
+    if (RTK_WALK_STATS >= 16 && ++stat_rounds == RTK_WALK_STATS) wc.exact += 1u;         // walks of at least that many rounds
+    if (RTK_WALK_STATS == 1) wc.exact += 1u;                                            // rounds of the walk's loop
+    if (RTK_WALK_STATS == 2) wc.exact += (unsigned)__builtin_popcountll(working);       // lanes that worked in them
+    if (RTK_WALK_STATS == 3 && waiting != 0ull && (__builtin_popcountll(waiting) >= 24 || working == 0ull)) wc.exact += 1u;  // rounds with an f64 phase
+#endif
     if (waiting != 0ull && (__builtin_popcountll(waiting) >= 24 || working == 0ull)) {
+#if !defined(RTK_WALK_STATS)
       wc.exact += (unsigned)__builtin_popcountll(waiting);
+#endif
       if (kept != 0u) {
         const uint32_t i = (uint32_t)__builtin_ctz(kept);
         kept &= kept - 1u;
@@ -639,7 +671,11 @@ __device__ __forceinline__ void closest_secondary(const DevScene& S, bool active
   }
   constexpr bool track = TRACK;
   closest_init(best);
+#if defined(RTK_HIT_CUT) && RTK_HIT_CUT == 3  // ... every ray walks, whatever its origin
+  const bool walks = active;
+#else
   const bool walks = active && grid_walk_applies(S, o, d);
+#endif
   if (walks) {
     for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
       const uint32_t obj = S.plane_object[ip];

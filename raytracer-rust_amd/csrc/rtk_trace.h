@@ -166,15 +166,20 @@ __device__ __forceinline__ void emit_children(const DevScene& S, const RTK_RO De
   }
 }
 
-// One node of the ray tree: `trace_inner` (src/scene.rs:141-153) for the ray (ro, rd) that enters the
-// pixel's colour with factor `weight`: closest hit, `apply_lighting` (src/scene.rs:172-205) with its
-// shadow rays, and the node's terms and children handed to `sink`.  camera_sweep: the ray is a camera
-// ray and the per-camera records may be used for its sweep.
-template <bool SECONDARY, bool PRIMARY_FILTER, int LB, bool WIDE, bool BRUTE, bool TRACK, typename Sink>
-__device__ __forceinline__ void trace_step(const DevScene& S, const float4* __restrict__ prim,
-                                           const float4* __restrict__ prim_cluster, bool have, bool camera_sweep, V3 ro, V3 rd,
-                                           double weight, int depth, Sink& sink, WaveCount& wc) {
-  const V3 scene_ambient = ld3(S.ambient);
+// One node of the ray tree, `trace_inner` (src/scene.rs:141-153) for the ray (ro, rd), in two halves.
+// find_hit: the closest hit and, where the hit's material reflects or transmits, the refractive index
+// n1 on the ray's side of the surface.  shade_hit: `apply_lighting` (src/scene.rs:172-205) with its
+// shadow rays for a ray that enters the pixel's colour with factor `weight`, the node's terms and
+// children handed to `sink`.  trace_step runs one after the other; the level-by-level order runs them
+// as two kernels, each with the registers of its half only.  camera_sweep: the ray is a camera ray
+// and the per-camera records may be used for its sweep.
+struct NodeHit {
+  double t, n1;
+  uint32_t obj;  // 0xffffffff: the ray leaves the scene
+};
+template <bool PRIMARY_FILTER, bool WIDE, bool BRUTE, bool TRACK>
+__device__ __forceinline__ NodeHit find_hit(const DevScene& S, const float4* __restrict__ prim, const float4* __restrict__ prim_cluster,
+                                            bool have, bool camera_sweep, V3 ro, V3 rd, int depth, WaveCount& wc) {
   {
     const unsigned n_camera = lanes_where(have && depth == 0);
     wc.primary += n_camera;
@@ -188,36 +193,45 @@ __device__ __forceinline__ void trace_step(const DevScene& S, const float4* __re
     closest_primary<TRACK>(S, prim, prim_cluster, have, ro, rd, best, wc, graze);
   else
     closest_secondary<WIDE, TRACK>(S, have, ro, rd, best, wc, graze);
+  NodeHit h;
+  h.t = best.t, h.n1 = 1.0;
+  h.obj = have ? best.obj : 0xffffffffu;
+  if constexpr (TRACK) {
+    // n1: material of the entry just before the hit in the sorted list, else 1.0 (1.0 either way when
+    // every refractivity in the scene is 1.0, track_n1 == 0).  Two roots within 1e-5 of each other
+    // make the reference's container list drop entries: then by the letter.
+    if (h.obj != 0xffffffffu) {
+      const RTK_RO DevObject& ob = S.objects[h.obj];
+      if (!is_approx_zero(ob.reflectivity) || !is_approx_zero(ob.transparency)) {
+        if (graze)
+          h.n1 = literal_n1(S, ro, rd, h.obj, best.t);
+        else if (best.prev_obj != 0xffffffffu)
+          h.n1 = S.objects[best.prev_obj].refractivity;
+      }
+    }
+  }
+  return h;
+}
 
-  const bool hit = have && best.obj != 0xffffffffu;
+template <bool SECONDARY, int LB, bool WIDE, bool BRUTE, typename Sink>
+__device__ __forceinline__ void shade_hit(const DevScene& S, bool have, const NodeHit& h, V3 ro, V3 rd, double weight, int depth,
+                                          Sink& sink, WaveCount& wc) {
+  const V3 scene_ambient = ld3(S.ambient);
+  const bool hit = have && h.obj != 0xffffffffu;
   if (have && !hit) sink.term(scene_ambient, weight);  // trace_inner: miss -> ambient_color
 
   // --- apply_lighting (src/scene.rs:172-205) ---
   V3 over = {0, 0, 0}, normal = {0, 0, 1}, eye = {0, 0, 1}, tex = {0, 0, 0};
-  uint32_t obj = hit ? best.obj : 0u;
+  const uint32_t obj = hit ? h.obj : 0u;
   if (hit) {
     const RTK_RO DevObject& ob = S.objects[obj];
-    HitGeom g = lighting_data(ob, ro, rd, best.t);
+    HitGeom g = lighting_data(ob, ro, rd, h.t);
     over = g.over;
     normal = g.normal;
     eye = g.eye;
     tex = sample_texture_at(S, ob, obj, g.objp);
-    if (SECONDARY) {
-      // children first, so that nothing of them stays live across the shadow sweep
-      double n1 = 1.0;
-      if constexpr (TRACK) {
-        // n1: material of the entry just before the hit in the sorted list, else 1.0 (1.0 either way when
-        // every refractivity in the scene is 1.0, track_n1 == 0).  Two roots within 1e-5 of each other
-        // make the reference's container list drop entries: then by the letter.
-        if (!is_approx_zero(ob.reflectivity) || !is_approx_zero(ob.transparency)) {
-          if (graze)
-            n1 = literal_n1(S, ro, rd, obj, best.t);
-          else if (best.prev_obj != 0xffffffffu)
-            n1 = S.objects[best.prev_obj].refractivity;
-        }
-      }
-      emit_children(S, ob, g, n1, weight, depth, sink);
-    }
+    // children first, so that nothing of them stays live across the shadow sweep
+    if (SECONDARY) emit_children(S, ob, g, h.n1, weight, depth, sink);
   }
 
 #if defined(RTK_NODE_CUT) && RTK_NODE_CUT >= 1  // experiment builds (wrong images): a node without its shadow rays
@@ -235,6 +249,14 @@ __device__ __forceinline__ void trace_step(const DevScene& S, const float4* __re
 #endif
     sink.term(surface, weight);
   }
+}
+
+template <bool SECONDARY, bool PRIMARY_FILTER, int LB, bool WIDE, bool BRUTE, bool TRACK, typename Sink>
+__device__ __forceinline__ void trace_step(const DevScene& S, const float4* __restrict__ prim,
+                                           const float4* __restrict__ prim_cluster, bool have, bool camera_sweep, V3 ro, V3 rd,
+                                           double weight, int depth, Sink& sink, WaveCount& wc) {
+  const NodeHit h = find_hit<PRIMARY_FILTER, WIDE, BRUTE, TRACK>(S, prim, prim_cluster, have, camera_sweep, ro, rd, depth, wc);
+  shade_hit<SECONDARY, LB, WIDE, BRUTE>(S, have, h, ro, rd, weight, depth, sink, wc);
 }
 
 // `Scene::trace` (src/scene.rs:136-138) for one ray per lane: the tree is walked with a stack per lane,

@@ -31,14 +31,18 @@ namespace rtk {
 #ifndef RTK_WF_OCC
 #define RTK_WF_OCC 4
 #endif
+#ifndef RTK_WF_GRID_MAX
+#define RTK_WF_GRID_MAX 65536u
+#endif
+#ifndef RTK_WF_HIT_OCC
+#define RTK_WF_HIT_OCC 4
+#endif
 
-// Start of a pass or of a level: [kCtrlLevelEnd + level] = nodes so far (at most the capacity).
-// set_nodes != 0 (start of a pass): the camera rays of the pass are nodes 0 .. set_nodes - 1.
-__global__ void wf_mark_kernel(unsigned int* ctrl, uint32_t level, uint32_t cap_nodes, uint32_t set_nodes) {
+// Start of a pass: the camera rays of the pass are nodes 0 .. n_roots - 1, and level 0 ends behind them.
+__global__ void wf_mark_kernel(unsigned int* ctrl, uint32_t cap_nodes, uint32_t n_roots) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (set_nodes) ctrl[kCtrlNodes] = set_nodes;
-  ctrl[kCtrlLevelEnd + level] = min(ctrl[kCtrlNodes], cap_nodes);
-  if (level > 0) ctrl[kCtrlClaim] = ctrl[kCtrlLevelEnd + level - 1];
+  ctrl[kCtrlNodes] = n_roots;
+  ctrl[kCtrlLevelEnd] = min(n_roots, cap_nodes);
 }
 
 // Level 0: the camera rays of the pass's tiles (ray generation: src/scene/cameras.rs:52-69 with the
@@ -66,37 +70,74 @@ __global__ void __launch_bounds__(kBlock, 4) wf_primary_kernel(DevScene S, DevCa
   flush_counts(counter_shard(B.counters), wc);
 }
 
-// Level l >= 1: the nodes queued by level l - 1 (all of depth l), one lane per node, 256 consecutive
-// queue entries per workgroup.  The claim counter may run past the level's end by 256 per workgroup of
-// the launch: far from wrapping for queues of up to 2^31 nodes.
-template <int LB, bool WIDE, bool TRACK>
-__global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_level_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
+// Level l >= 1: the nodes queued by level l - 1 (all of depth l), one lane per node, in two launches.
+// The first finds every node's closest hit (and n1) and leaves it in the node's result record; the
+// second shades the hits, queues the children and overwrites the record with the node's terms.  Two
+// kernels because either half alone needs far fewer registers than both together: the first, whose lanes
+// spend their time waiting for the cells and lists of their walks, then has twice the wavefronts in
+// flight to wait with.
+struct WfNodeHit {  // what the first launch leaves at the start of a node's WfNodeOut
+  double t, n1;
+  uint32_t obj, reserved_;
+};
+static_assert(sizeof(WfNodeHit) <= sizeof(WfNodeOut), "a node's hit lies inside its result record");
+
+template <bool WIDE, bool TRACK>
+__global__ void __launch_bounds__(kBlock, RTK_WF_HIT_OCC) wf_hit_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
+  // the level ends where the queue ends now: nothing is queued while this kernel runs.  The kernel that
+  // shades the level queues the next one's nodes as it goes, so the end is written down for it.
+  const uint32_t end = min(B.ctrl[kCtrlNodes], B.cap_nodes);
+  if (blockIdx.x == 0 && threadIdx.x == 0) B.ctrl[kCtrlLevelEnd + level] = end;
+  const uint32_t lane = threadIdx.x & 63u;
+  WaveCount wc;
+  // Wavefronts take the level's nodes 64 at a time, dealt round-robin.  (Handing them out through a
+  // counter in memory costs more than the uneven shares it avoids: one address takes an atomic every
+  // 12 ns or so, and a level has tens of thousands of wavefronts' worth of nodes.)
+  const uint32_t begin = B.ctrl[kCtrlLevelEnd + level - 1];
+  const uint32_t n_waves = gridDim.x * (kBlock / 64u), wave = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6);
+  for (uint32_t first = begin + wave * 64u; first < end; first += n_waves * 64u) {
+    const uint32_t i = first + lane;
+    const bool have = i < end;
+    V3 ro = {0, 0, 0}, rd = {0, 0, 1};
+    if (have) {
+      const WfNodeRay& r = B.rays[i - n_roots];
+      ro = {r.o[0], r.o[1], r.o[2]};
+      rd = {r.d[0], r.d[1], r.d[2]};
+    }
+    const NodeHit h = find_hit<false, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, (int)level, wc);
+    if (have) {
+      WfNodeHit& out = *reinterpret_cast<WfNodeHit*>(&B.outs[i]);
+      out.t = h.t, out.n1 = h.n1, out.obj = h.obj;
+    }
+  }
+  flush_counts(counter_shard(B.counters), wc);
+}
+
+template <int LB, bool WIDE>
+__global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_shade_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
   const uint32_t end = B.ctrl[kCtrlLevelEnd + level];
   WaveCount wc;
   __shared__ ParkedChild s_park[2 * kBlock];
   __shared__ uint32_t s_counts[10];
-  __shared__ uint32_t s_base;
-  // workgroups take 256 nodes at a time from the level's counter (nodes cost very different amounts),
-  // one lane per node, and queue the children of the 256 together
-  for (;;) {
-    if (threadIdx.x == 0) s_base = atomicAdd(&B.ctrl[kCtrlClaim], (unsigned int)kBlock);
-    __syncthreads();
-    const uint32_t base = s_base;
-    if (base >= end) break;
+  // workgroups take 256 nodes at a time, dealt round-robin, one lane per node, and queue the children of the 256 together
+  const uint32_t begin = B.ctrl[kCtrlLevelEnd + level - 1];
+  for (uint32_t base = begin + blockIdx.x * kBlock; base < end; base += gridDim.x * kBlock) {
     const uint32_t i = base + threadIdx.x;
     const bool have = i < end;
     V3 ro = {0, 0, 0}, rd = {0, 0, 1};
     double weight = 0.0;
+    NodeHit h = {0.0, 1.0, 0xffffffffu};
     if (have) {
       const WfNodeRay& r = B.rays[i - n_roots];
       ro = {r.o[0], r.o[1], r.o[2]};
       rd = {r.d[0], r.d[1], r.d[2]};
       weight = r.weight;
+      const WfNodeHit& in = *reinterpret_cast<const WfNodeHit*>(&B.outs[i]);
+      h.t = in.t, h.n1 = in.n1, h.obj = in.obj;
     }
     ParkSink sink(s_park);
-    if (__any(have))
-      trace_step<true, false, LB, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, weight, (int)level, sink, wc);
-    sink.flush(B, n_roots, level + 1u, s_counts);  // its barriers also keep s_base until every thread has read it
+    if (__any(have)) shade_hit<true, LB, WIDE, false>(S, have, h, ro, rd, weight, (int)level, sink, wc);
+    sink.flush(B, n_roots, level + 1u, s_counts);
     if (have) sink.store(B.outs[i]);
   }
   flush_counts(counter_shard(B.counters), wc);
@@ -149,13 +190,13 @@ __global__ void __launch_bounds__(kCounterShards) wf_commit_kernel(const unsigne
 bool wavefront_applies(const DevScene& S) { return S.any_secondary && S.n_objects > kBruteObjects && S.max_depth >= 2; }
 
 // ... and launches small enough for the depth-first kernel's last pixels to matter.  That kernel
-// spends a fixed time on its slowest pixels (about 3 ms with 157 clusters, 1.5 ms with 16, 0.5 ms with
-// one) and then 10-20 % less per pixel than the queue does (which moves 256 bytes per node and makes
-// the wavefronts of a workgroup wait for each other), so from some launch size on it is the faster
-// one: the measured cross-overs are 10.4 Mpixel for 10,000 spheres, 9.4 Mpixel for 1,000, and about
-// 5 Mpixel for 64.
+// spends a fixed time on its slowest pixels (a wavefront stays for as long as its deepest ray tree
+// takes) and then less per pixel than the queue does, which moves a few hundred bytes per node through
+// memory; from some launch size on it is the faster one.  Measured on glass scenes of 10,000 / 1,000 /
+// 64 spheres: the queue wins at 2 Mpixel by 24 % / 23 % / -, is level at 8.3 Mpixel with 10,000
+// spheres (5.31 against 5.41 ms) and behind there with 1,000 (4.68 against 4.49 ms) and with 64.
 bool wavefront_pays(const DevScene& S, uint64_t launch_pixels) {
-  return launch_pixels <= (S.n_spheres >= 256u ? 10000000ull : 5000000ull);
+  return launch_pixels <= (S.n_spheres >= 4096u ? 10000000ull : 5000000ull);
 }
 
 namespace {
@@ -172,14 +213,14 @@ hipError_t launch_primary_lb(int lb, dim3 grid, hipStream_t st, const DevScene& 
   return hipGetLastError();
 }
 
-template <bool WIDE, bool TRACK>
-hipError_t launch_level_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, uint32_t level, uint32_t n_roots,
+template <bool WIDE>
+hipError_t launch_shade_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, uint32_t level, uint32_t n_roots,
                            const WavefrontBuffers& B) {
   switch (lb) {
-    case 1: hipLaunchKernelGGL((wf_level_kernel<1, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
-    case 2: hipLaunchKernelGGL((wf_level_kernel<2, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
-    case 4: hipLaunchKernelGGL((wf_level_kernel<4, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
-    default: hipLaunchKernelGGL((wf_level_kernel<8, WIDE, TRACK>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    case 1: hipLaunchKernelGGL((wf_shade_kernel<1, WIDE>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    case 2: hipLaunchKernelGGL((wf_shade_kernel<2, WIDE>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    case 4: hipLaunchKernelGGL((wf_shade_kernel<4, WIDE>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    default: hipLaunchKernelGGL((wf_shade_kernel<8, WIDE>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
   }
   return hipGetLastError();
 }
@@ -201,7 +242,7 @@ hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevC
   for (uint32_t tile_base = 0; tile_base < T.n_local_tiles; tile_base += pass_tiles) {
     const uint32_t n_tiles = std::min(pass_tiles, T.n_local_tiles - tile_base);
     const uint32_t n_roots = n_tiles * kBlock;
-    hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(64), 0, st, B.ctrl, 0u, B.cap_nodes, n_roots);
+    hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(64), 0, st, B.ctrl, B.cap_nodes, n_roots);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const dim3 grid(n_tiles);
     // the camera level: on the opaque path's bundle tests where they apply, else through trace_step
@@ -213,13 +254,17 @@ hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevC
     if (e != hipSuccess) return e;
     // levels 1 .. max_depth - 1 (nodes at depth max_depth are not traced: their parents account for them);
     // enough resident workgroups to fill the GPU, no more than the pass could ever need
-    const dim3 level_grid(std::min<uint32_t>(1024u, std::max<uint32_t>(1u, n_tiles * 2u)));
+    // One workgroup per tile of the pass: a level usually has fewer nodes than the pass has pixels, so most
+    // workgroups take one run of 256 nodes (or none) and the hardware's dispatcher evens out what the nodes
+    // cost; a level with more nodes than that gives every workgroup several runs.
+    const dim3 level_grid(std::min<uint32_t>(RTK_WF_GRID_MAX, n_tiles)), hit_grid = level_grid;
     for (uint32_t level = 1; level < S.max_depth; ++level) {
-      hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(64), 0, st, B.ctrl, level, B.cap_nodes, 0u);
+      if (track)
+        hipLaunchKernelGGL((wf_hit_kernel<true, true>), hit_grid, dim3(kBlock), 0, st, S, level, n_roots, B);
+      else
+        hipLaunchKernelGGL((wf_hit_kernel<true, false>), hit_grid, dim3(kBlock), 0, st, S, level, n_roots, B);
       if ((e = hipGetLastError()) != hipSuccess) return e;
-      e = track ? launch_level_lb<true, true>(lb, level_grid, st, S, level, n_roots, B)
-                : launch_level_lb<true, false>(lb, level_grid, st, S, level, n_roots, B);
-      if (e != hipSuccess) return e;
+      if ((e = launch_shade_lb<true>(lb, level_grid, st, S, level, n_roots, B)) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(wf_gather_kernel, grid, dim3(kBlock), 0, st, S, C, T, tile_base, B.outs);
     if ((e = hipGetLastError()) != hipSuccess) return e;

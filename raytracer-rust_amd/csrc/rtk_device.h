@@ -147,7 +147,9 @@ struct DevScene {
   uint32_t k_width;        // lights per k_table row (4 or 8)
   uint32_t shadow_grid;    // the light grids exist (lights_uniform scenes with secondary rays and a cluster hierarchy)
   uint32_t trace_grid;     // the cell grid exists
+  uint32_t lights_point;   // every light has w == 1 (built from a point): shadow rays are plain segments
   uint32_t tg_n[3];
+  uint32_t reserved_;
   double tg_lo[3], tg_inv_h;
   double center[3];      // recentring offset of the FP32 filter
   double ambient[3];

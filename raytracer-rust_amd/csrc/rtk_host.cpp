@@ -839,7 +839,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   // Lights with w == 1 (built from points): plain segments from the shading point to the light;
   // the bundle of a patch is a cone with its apex at the light.  Their record is the light's
   // position, recentred like the sphere records.  lights_bundled: every light is one or the other.
-  bool lights_uniform = scene->n_lights > 0, lights_bundled = scene->n_lights > 0;
+  bool lights_uniform = scene->n_lights > 0, lights_bundled = scene->n_lights > 0, lights_point = scene->n_lights > 0;
   std::vector<double> gd(4 * (size_t)scene->n_lights);
   for (uint32_t k = 0; k < scene->n_lights; ++k) {
     const double* L = scene->lights[k].position;
@@ -848,6 +848,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
       lights_uniform = false;
       continue;
     }
+    lights_point = false;
     if (L[3] != 0.0 || !(gg > 0.0) || !std::isfinite(gg)) {
       lights_uniform = false;
       lights_bundled = false;
@@ -1095,6 +1096,7 @@ static int flatten_scene_checked(const rtk_scene* scene, rtk::FlatScene& flat) {
   d.k_width = k_width;
   d.shadow_grid = shadow_grid ? 1u : 0u;
   d.trace_grid = trace_grid ? 1u : 0u;
+  d.lights_point = lights_point ? 1u : 0u;
   if (trace_grid) {
     for (int a = 0; a < 3; ++a) d.tg_lo[a] = tgrid.lo[a], d.tg_n[a] = tgrid.n[a];
     d.tg_inv_h = tgrid.inv_h;
@@ -1263,7 +1265,7 @@ uint64_t rtk::flat_scene_digest(const rtk::FlatScene& flat) {
   const rtk::DevScene& d = flat.dev;
   for (uint32_t v : {d.n_objects, d.n_lights, d.n_spheres, d.n_spheres_padded, d.n_planes, d.n_clusters_padded, d.n_spheres_grouped,
                      d.max_depth, d.track_n1, d.any_secondary, d.lights_uniform, d.lights_bundled, d.k_width, d.shadow_grid,
-                     d.trace_grid, d.tg_n[0], d.tg_n[1], d.tg_n[2]})
+                     d.trace_grid, d.lights_point, d.tg_n[0], d.tg_n[1], d.tg_n[2]})
     word(v);
   bytes(d.tg_lo, sizeof d.tg_lo), bytes(&d.tg_inv_h, sizeof d.tg_inv_h);
   bytes(d.center, sizeof d.center), bytes(d.ambient, sizeof d.ambient);

@@ -353,8 +353,8 @@ __device__ __forceinline__ bool shadow_by_grids(const DevScene& S, bool active, 
   bool in_shadow = false;
   const bool swept = active && !in_range;
 #endif
-  if (__any(swept)) {
-    const bool s = shadow_by_sweeps<LB, WIDE>(S, swept, p, wc);
+  if (__any(swept)) {  // (one light at a time: the same rays, and fewer registers on a way few points take)
+    const bool s = shadow_by_sweeps<1, WIDE>(S, swept, p, wc);
     if (swept) in_shadow = s;
   }
   const float thr = filter_threshold(S, pc, rho_max);
@@ -432,12 +432,6 @@ __device__ __forceinline__ bool shadow_by_grids(const DevScene& S, bool active, 
   return in_shadow;
 }
 
-template <int LB, bool WIDE>
-__device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3 p, WaveCount& wc) {
-  if (WIDE && S.shadow_grid) return shadow_by_grids<LB, WIDE>(S, active, p, wc);
-  return shadow_by_sweeps<LB, WIDE>(S, active, p, wc);
-}
-
 // ------------------------------------------------------------------------------------
 // Closest hit of a general ray (origin o, direction d with w = 0, not necessarily unit):
 // `Scene::intersect` + `HitList::closest_hit` (src/scene.rs:156-169, 325-340).
@@ -495,12 +489,13 @@ __device__ __forceinline__ void closest_general(const DevScene& S, bool active, 
 //
 // Lanes whose filter kept a sphere wait with it until 24 of them do, or until no lane has anything
 // else to do: the f64 test then runs for all of them at once instead of once per lane and candidate.
-// backward: the walk runs against the ray's direction and ends behind the largest root <= 0 (the
-// entry before the winner, whose material is n1).
-template <bool TRACK>
-__device__ __forceinline__ void grid_walk(const DevScene& S, bool active, V3 o, V3 d, bool backward, Closest& best,
-                                          WaveCount& wc, bool& graze) {
-  constexpr bool track = TRACK;
+// backward: the walk runs against the ray's direction.  t_stop: the ray parameter (in units of d, counted
+// along the walk) behind which nothing matters to the caller -- the best root so far of a closest-hit
+// search, the light's distance for a shadow ray; exact(sweep position) runs the caller's f64 test on a
+// sphere the filter kept and returns the t_stop that holds from then on (negative: the lane's walk ends).
+template <typename ExactFn>
+__device__ __forceinline__ void grid_march(const DevScene& S, bool active, V3 o, V3 d, bool backward, double t_stop,
+                                           WaveCount& wc, ExactFn&& exact) {
   const double dd = dot3(d, d);
   const double rs = __builtin_amdgcn_rsq(dd);  // relative error about 1e-8: the walk needs a direction, not the direction
   const double sign = backward ? -1.0 : 1.0;
@@ -548,12 +543,9 @@ __device__ __forceinline__ void grid_walk(const DevScene& S, bool active, V3 o, 
   const V3 pc = {o.x - S.center[0], o.y - S.center[1], o.z - S.center[2]};
   const float px = (float)pc.x, py = (float)pc.y, pz = (float)pc.z;
   const float thr = filter_threshold(S, pc, 0.0f);
-  // the best root so far in the walk's units (distance from the walk's first point, in cells)
-  auto best_at = [&]() -> float {
-    const double t = backward ? -best.prev_t : best.t;  // DBL_MAX without one: stays beyond every cell
-    return (float)fmin(__builtin_fma(t, len_h, -s_in), 1.0e30);
-  };
-  float best_u = best_at();
+  // t_stop in the walk's units (distance from the walk's first point, in cells); DBL_MAX stays beyond every cell
+  auto in_cells = [&](double t) -> float { return (float)fmin(__builtin_fma(t, len_h, -s_in), 1.0e30); };
+  float best_u = in_cells(t_stop);
   uint32_t first = 0, count = 0, base = 0;  // the current cell's list, and how much of it is done
   uint32_t kept = 0u, slot[4] = {0u, 0u, 0u, 0u}, seen0 = 0xffffffffu, seen1 = 0xffffffffu;
   int budget = (int)(S.tg_n[0] + S.tg_n[1] + S.tg_n[2]) + 4;  // cells a straight line can cross
@@ -634,14 +626,9 @@ __device__ __forceinline__ void grid_walk(const DevScene& S, bool active, V3 o, 
         kept &= kept - 1u;
         const uint32_t at = i == 0u ? slot[0] : (i == 1u ? slot[1] : (i == 2u ? slot[2] : slot[3]));
         seen1 = seen0, seen0 = at;
-        const RTK_RO SphRecord& rec = S.sph_record[at];
-        double t0, t1;
-        if (intersect_sphere_record(S, rec, o, d, 0.0, t0, t1)) {
-          closest_consider(best, t0, rec.object, track);
-          closest_consider(best, t1, rec.object, track);
-          if (track && fabs(t0 - t1) < 0.00001) graze = true;  // `Hit::eq` would call the two roots one hit
-          best_u = best_at();
-        }
+        const double stop = exact(at);
+        best_u = in_cells(stop);
+        if (stop < 0.0) alive = false, kept = 0u;  // the caller has its answer
       }
     } else if (working == 0ull) {
       break;  // nobody waits, nobody works
@@ -694,7 +681,20 @@ __device__ __forceinline__ void closest_secondary(const DevScene& S, bool active
         go = !is_approx_zero(ob.reflectivity) || !is_approx_zero(ob.transparency);
       }
     }
-    if (__any(go)) grid_walk<TRACK>(S, go, o, d, pass == 1, best, wc, graze);
+    if (__any(go)) {
+      const bool backward = pass == 1;
+      auto exact = [&](uint32_t at) -> double {
+        const RTK_RO SphRecord& rec = S.sph_record[at];
+        double t0, t1;
+        if (intersect_sphere_record(S, rec, o, d, 0.0, t0, t1)) {
+          closest_consider(best, t0, rec.object, track);
+          closest_consider(best, t1, rec.object, track);
+          if (track && fabs(t0 - t1) < 0.00001) graze = true;  // `Hit::eq` would call the two roots one hit
+        }
+        return backward ? -best.prev_t : best.t;
+      };
+      grid_march(S, go, o, d, backward, backward ? -best.prev_t : best.t, wc, exact);
+    }
   }
   const bool swept = active && !walks;
   if (__any(swept)) {
@@ -728,6 +728,74 @@ __device__ __forceinline__ void closest_primary(const DevScene& S, const float4*
     }
   };
   sweep_primary(S, prim, prim_cluster, active, (float)d.x, (float)d.y, (float)d.z, wc, exact);
+}
+
+// ------------------------------------------------------------------------------------
+// `Scene::is_shadowed` for shading points that have nothing to do with each other, towards lights built
+// from points (w = 1): the shadow ray is a plain segment from the point to the light, and every lane
+// walks ITS segment through the cell grid, light after light until one is blocked.  Points from which
+// the walk cannot start (grid_walk_applies) take the cluster sweeps.
+template <int LB, bool WIDE>
+__device__ __forceinline__ bool shadow_by_walks(const DevScene& S, bool active, V3 p, WaveCount& wc) {
+  // a segment that ends at the light: its direction has the length of the light's distance, never zero
+  // for a point that is not the light itself (such a point sweeps)
+  bool walks = active;
+  for (uint32_t k = 0; k < S.n_lights; ++k) walks = walks && grid_walk_applies(S, p, ld3(S.lights[k].pos) - p);
+  bool in_shadow = false;
+  const bool swept = active && !walks;
+  if (__any(swept)) {  // (one light at a time: the same rays, and fewer registers on a way few points take)
+    const bool s = shadow_by_sweeps<1, WIDE>(S, swept, p, wc);
+    if (swept) in_shadow = s;
+  }
+  bool need = walks;
+  for (uint32_t k = 0; k < S.n_lights; ++k) {
+    if (!__any(need)) break;
+    const RTK_RO DevLight& L = S.lights[k];
+    // the reference's shadow ray towards this light (src/scene.rs:208-225); w = 1: direction.w = 0
+    const V3 lv = ld3(L.pos) - p;
+    const double lw = L.pos[3] - 1.0;
+    const double m = sqrt_f64(lv.x * lv.x + lv.y * lv.y + lv.z * lv.z + lw * lw);
+    double dw;
+    const V3 d = divide_by_length(lv, lw, m, dw);
+    wc.shadow += lanes_where(need);
+    bool blocked = false;
+    if (need) {
+      for (uint32_t ip = 0; ip < S.n_planes; ++ip) {  // planes: exact
+        const RTK_RO DevObject& ob = S.objects[S.plane_object[ip]];
+        if (!plane_may_block(plane_side(ob, p), S.plane_light[ip * S.n_lights + k])) continue;
+        double t0, t1;
+        const int n = intersect_object(ob, p, d, dw, t0, t1);
+        if (n >= 1 && t0 > 0.0 && t0 < m) blocked = true;
+      }
+    }
+    const bool go = need && !blocked;
+    if (__any(go)) {
+      auto exact = [&](uint32_t at) -> double {
+        const RTK_RO SphRecord& rec = S.sph_record[at];
+        double t0, t1;
+        const int n = intersect_sphere_record(S, rec, p, d, dw, t0, t1);
+        if (n == 2 && ((t0 > 0.0 && t0 < m) || (t1 > 0.0 && t1 < m))) {
+          blocked = true;
+          return -1.0;
+        }
+        return m;
+      };
+      grid_march(S, go, p, d, false, m, wc, exact);  // |d| = 1 up to rounding: the walk stops behind the light
+    }
+    if (need && blocked) in_shadow = true, need = false;
+  }
+  return in_shadow;
+}
+
+// Which of the three a scene's shading points take.  A kernel built for one of them (HOW >= 0, chosen by
+// the host with shadow_mode) carries that one and the sweeps it falls back to, not all three.
+constexpr int kShadowSweeps = 0, kShadowGrids = 1, kShadowWalks = 2, kShadowAny = -1;
+template <int LB, bool WIDE, int HOW = kShadowAny>
+__device__ __forceinline__ bool shadow_sweeps(const DevScene& S, bool active, V3 p, WaveCount& wc) {
+  if (WIDE && (HOW == kShadowGrids || (HOW == kShadowAny && S.shadow_grid))) return shadow_by_grids<LB, WIDE>(S, active, p, wc);
+  if (WIDE && (HOW == kShadowWalks || (HOW == kShadowAny && !S.shadow_grid && S.trace_grid && S.lights_point)))
+    return shadow_by_walks<LB, WIDE>(S, active, p, wc);
+  return shadow_by_sweeps<LB, WIDE>(S, active, p, wc);
 }
 
 }  // namespace rtk

@@ -213,7 +213,7 @@ __device__ __forceinline__ NodeHit find_hit(const DevScene& S, const float4* __r
   return h;
 }
 
-template <bool SECONDARY, int LB, bool WIDE, bool BRUTE, typename Sink>
+template <bool SECONDARY, int LB, bool WIDE, bool BRUTE, int SHADOWS = kShadowAny, typename Sink>
 __device__ __forceinline__ void shade_hit(const DevScene& S, bool have, const NodeHit& h, V3 ro, V3 rd, double weight, int depth,
                                           Sink& sink, WaveCount& wc) {
   const V3 scene_ambient = ld3(S.ambient);
@@ -237,7 +237,7 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, bool have, const No
 #if defined(RTK_NODE_CUT) && RTK_NODE_CUT >= 1  // experiment builds (wrong images): a node without its shadow rays
   const bool in_shadow = false;
 #else
-  const bool in_shadow = BRUTE ? shadow_brute(S, hit, over, wc) : shadow_sweeps<LB, WIDE>(S, hit, over, wc);
+  const bool in_shadow = BRUTE ? shadow_brute(S, hit, over, wc) : shadow_sweeps<LB, WIDE, SHADOWS>(S, hit, over, wc);
 #endif
 
   if (hit) {

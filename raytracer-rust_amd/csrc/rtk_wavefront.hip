@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(kBlock, RTK_WF_HIT_OCC) wf_hit_kernel(DevScene
   flush_counts(counter_shard(B.counters), wc);
 }
 
-template <int LB, bool WIDE>
+template <int LB, bool WIDE, int SHADOWS>
 __global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_shade_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
   const uint32_t end = B.ctrl[kCtrlLevelEnd + level];
   WaveCount wc;
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_shade_kernel(DevScene S
       h.t = in.t, h.n1 = in.n1, h.obj = in.obj;
     }
     ParkSink sink(s_park);
-    if (__any(have)) shade_hit<true, LB, WIDE, false>(S, have, h, ro, rd, weight, (int)level, sink, wc);
+    if (__any(have)) shade_hit<true, LB, WIDE, false, SHADOWS>(S, have, h, ro, rd, weight, (int)level, sink, wc);
     sink.flush(B, n_roots, level + 1u, s_counts);
     if (have) sink.store(B.outs[i]);
   }
@@ -213,16 +213,23 @@ hipError_t launch_primary_lb(int lb, dim3 grid, hipStream_t st, const DevScene& 
   return hipGetLastError();
 }
 
-template <bool WIDE>
+template <bool WIDE, int SHADOWS>
 hipError_t launch_shade_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, uint32_t level, uint32_t n_roots,
                            const WavefrontBuffers& B) {
   switch (lb) {
-    case 1: hipLaunchKernelGGL((wf_shade_kernel<1, WIDE>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
-    case 2: hipLaunchKernelGGL((wf_shade_kernel<2, WIDE>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
-    case 4: hipLaunchKernelGGL((wf_shade_kernel<4, WIDE>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
-    default: hipLaunchKernelGGL((wf_shade_kernel<8, WIDE>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    case 1: hipLaunchKernelGGL((wf_shade_kernel<1, WIDE, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    case 2: hipLaunchKernelGGL((wf_shade_kernel<2, WIDE, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    case 4: hipLaunchKernelGGL((wf_shade_kernel<4, WIDE, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    default: hipLaunchKernelGGL((wf_shade_kernel<8, WIDE, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
   }
   return hipGetLastError();
+}
+
+// How the shading points of a scene's secondary hits look for their blockers (shadow_sweeps).
+int shadow_mode(const DevScene& S) {
+  if (S.shadow_grid) return kShadowGrids;
+  if (S.trace_grid && S.lights_point) return kShadowWalks;
+  return kShadowSweeps;
 }
 
 }  // namespace
@@ -264,7 +271,12 @@ hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevC
       else
         hipLaunchKernelGGL((wf_hit_kernel<true, false>), hit_grid, dim3(kBlock), 0, st, S, level, n_roots, B);
       if ((e = hipGetLastError()) != hipSuccess) return e;
-      if ((e = launch_shade_lb<true>(lb, level_grid, st, S, level, n_roots, B)) != hipSuccess) return e;
+      switch (shadow_mode(S)) {
+        case kShadowGrids: e = launch_shade_lb<true, kShadowGrids>(lb, level_grid, st, S, level, n_roots, B); break;
+        case kShadowWalks: e = launch_shade_lb<true, kShadowWalks>(lb, level_grid, st, S, level, n_roots, B); break;
+        default: e = launch_shade_lb<true, kShadowSweeps>(lb, level_grid, st, S, level, n_roots, B); break;
+      }
+      if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(wf_gather_kernel, grid, dim3(kBlock), 0, st, S, C, T, tile_base, B.outs);
     if ((e = hipGetLastError()) != hipSuccess) return e;

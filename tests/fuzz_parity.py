@@ -2,7 +2,8 @@
 
     python tests/fuzz_parity.py [n_scenes] [seed]          (FUZZ_BIG=1: thousands of spheres per scene;
                                                             FUZZ_GLASS=1: hundreds to thousands of spheres, always
-                                                            glass, always w = 0 lights: the light grids and the
+                                                            glass, always w = 0 lights (FUZZ_LIGHTS=w1 / mixed /
+                                                            exotic: those instead): the light grids and the
                                                             level-by-level order, at frame sizes either side of
                                                             the library's choice between the two orders)
 
@@ -59,7 +60,7 @@ def random_scene(rtk, rng):
             m = m.with_transparency(0.9).with_reflective(0.9).with_ambient(0.2).with_diffuse(0.2).with_refractivity(
                 float(rng.choice([1.0, 1.5])))
         scene.add_object(rtk.Sphere().with_material(m).with_transform(t))
-    kinds = "w0" if only_glass else rng.choice(["w0", "w1", "mixed", "exotic"], p=[0.4, 0.25, 0.25, 0.1])
+    kinds = os.environ.get("FUZZ_LIGHTS") or ("w0" if only_glass else rng.choice(["w0", "w1", "mixed", "exotic"], p=[0.4, 0.25, 0.25, 0.1]))
     for k in range(int(rng.integers(1, 7))):
         near = rng.random() < 0.4
         pos = offset + (rng.normal(size=3) * extent * (0.3 if near else 3.0) + np.array([0, extent * (0.5 if near else 2.0), 0]))

@@ -848,15 +848,16 @@ __global__ void __launch_bounds__(64, 5) render_uniform_kernel(DevScene S, DevCa
 // the pixel is not stored -- what the camera ray's node adds to it goes to the node's record, and the
 // reflected and refracted children of the hit are queued.  For scenes whose lights all have w = 0
 // and whose refractive indices are all equal (n1 = 1 on every camera ray); one workgroup per tile,
-// node = workgroup * 256 + thread.  Three wavefronts per SIMD: the parked children take 28 KB of LDS
-// next to the 18 KB of hit geometry.
+// node = workgroup * 256 + thread.
+#ifndef RTK_QP_OCC
+#define RTK_QP_OCC 5
+#endif
 template <int KW>
-__global__ void __launch_bounds__(kBlock, 3) queue_primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
+__global__ void __launch_bounds__(kBlock, RTK_QP_OCC) queue_primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                                  const float4* __restrict__ prim_ball,
                                                                  const float4* __restrict__ prim_cluster, RenderTarget T,
                                                                  uint32_t tile_base, WavefrontBuffers B) {
   __shared__ Stash stash;
-  __shared__ ParkedChild s_park[2 * kBlock];
   __shared__ uint32_t s_counts[10];
   const PixelRef px = pixel_ref(T, C, tile_base + blockIdx.x);
   Closest best;
@@ -865,7 +866,7 @@ __global__ void __launch_bounds__(kBlock, 3) queue_primary_kernel(DevScene S, De
   primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, wc, &stash);
   const uint32_t obj = px.valid ? best.obj : 0xffffffffu;
   const bool hit = obj != 0xffffffffu;
-  ParkSink sink(s_park);
+  QueueSink sink(B, gridDim.x * kBlock, 1u, s_counts);
   V3 p = {0, 0, 0};
   if (hit) {
     const RTK_RO DevObject& ob = S.objects[obj];
@@ -875,6 +876,7 @@ __global__ void __launch_bounds__(kBlock, 3) queue_primary_kernel(DevScene S, De
     p = g.over;
     emit_children(S, ob, g, 1.0, 1.0, 0, sink);  // children first: nothing of them stays live across the shadow phase
   }
+  sink.children_done();
   const bool in_shadow = shadow_phase_uniform<KW>(S, hit, p, wc);
   if (px.valid) {
     if (hit)
@@ -882,7 +884,6 @@ __global__ void __launch_bounds__(kBlock, 3) queue_primary_kernel(DevScene S, De
     else
       sink.term(ld3(S.ambient), 1.0);  // trace_inner: miss -> ambient_color
   }
-  sink.flush(B, gridDim.x * kBlock, 1u, s_counts);
   sink.store(B.outs[blockIdx.x * kBlock + threadIdx.x]);
   flush_counts(counter_shard(B.counters), wc);
 }

@@ -18,23 +18,27 @@ constexpr int kCtrlLevelEnd = 3;  // [kCtrlLevelEnd + l]: one past the last node
 static_assert(kCtrlLevelEnd + kMaxDepth < (int)kWavefrontCtrlWords, "one level end per depth fits the control block");
 
 // Result sink for one node of the level-by-level order: keeps the node's terms and queues its
-// children.  The workgroups of these kernels move in step (one node per lane, then all together): a
-// node's children are parked in LDS, and when every wavefront of the workgroup has traced its node
-// the workgroup takes ONE run of queue positions for all of them -- the refracted children in
-// thread order, then the reflected ones.  Children of neighbouring parents so stay neighbours in the
-// queue whatever other workgroups push meanwhile, and the next level's wavefronts (64 consecutive
-// entries each) open few clusters.
-struct ParkedChild {
-  double o[3], d[3], weight;
-};
-struct ParkSink {
+// children.  The workgroups of these kernels move in step (one node per lane, then all together): when
+// every lane has formed the children of its hit (children_done, which every thread of the workgroup
+// calls once per node, at the same point), the workgroup takes ONE run of queue positions for all of
+// them -- the refracted children in thread order, then the reflected ones -- and every lane writes its
+// children there straight from its registers, which are free again before the shadow rays start.
+// Children of neighbouring parents so stay neighbours in the queue whatever other workgroups push
+// meanwhile, and the next level's wavefronts (64 consecutive entries each) start close together.
+struct QueueSink {
   V3 t = {0, 0, 0};
   double w_refraction = 0.0, w_reflection = 0.0;
   uint32_t child_refraction = kNoNode, child_reflection = kNoNode, flags = 0;
-  bool parked_refraction = false, parked_reflection = false;
-  ParkedChild* park;  // LDS, [2][kBlock]: refracted, reflected
+  // the children, from sink.child() until children_done()
+  V3 o_refraction = {0, 0, 0}, d_refraction = {0, 0, 0}, o_reflection = {0, 0, 0}, d_reflection = {0, 0, 0};
+  double weight_refraction = 0.0, weight_reflection = 0.0;
+  bool has_refraction = false, has_reflection = false;
+  const WavefrontBuffers& B;
+  uint32_t n_roots, child_depth;
+  uint32_t* s_counts;  // 10 words of LDS
 
-  __device__ __forceinline__ explicit ParkSink(ParkedChild* lds) : park(lds) {}
+  __device__ __forceinline__ QueueSink(const WavefrontBuffers& buffers, uint32_t roots, uint32_t depth_of_children, uint32_t* lds_counts)
+      : B(buffers), n_roots(roots), child_depth(depth_of_children), s_counts(lds_counts) {}
   __device__ __forceinline__ void term(V3 v, double w) {
     t = v * w;
     flags |= kHasTerm;
@@ -46,19 +50,14 @@ struct ParkSink {
       w_refraction = w, flags |= kUntracedRefraction;
   }
   __device__ __forceinline__ void child(bool reflection, V3 o, V3 d, double w, int) {
-    ParkedChild& c = park[(reflection ? kBlock : 0) + threadIdx.x];
-    c.o[0] = o.x, c.o[1] = o.y, c.o[2] = o.z;
-    c.d[0] = d.x, c.d[1] = d.y, c.d[2] = d.z;
-    c.weight = w;
     if (reflection)
-      parked_reflection = true;
+      o_reflection = o, d_reflection = d, weight_reflection = w, has_reflection = true;
     else
-      parked_refraction = true;
+      o_refraction = o, d_refraction = d, weight_refraction = w, has_refraction = true;
   }
-  // Every thread of the workgroup calls this once its node is traced.  s_counts: 10 words of LDS.
-  __device__ __forceinline__ void flush(const WavefrontBuffers& B, uint32_t n_roots, uint32_t child_depth, uint32_t* s_counts) {
+  __device__ __forceinline__ void children_done() {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(parked_refraction), m1 = __builtin_amdgcn_ballot_w64(parked_reflection);
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(has_refraction), m1 = __builtin_amdgcn_ballot_w64(has_reflection);
     if (lane == 0) {
       s_counts[wave] = (uint32_t)__builtin_popcountll(m0);
       s_counts[4u + wave] = (uint32_t)__builtin_popcountll(m1);
@@ -76,16 +75,15 @@ struct ParkSink {
       if (w < wave) before0 += s_counts[w], before1 += s_counts[4u + w];
     }
     const uint32_t base = s_counts[8];
-    auto place = [&](bool parked, unsigned long long m, uint32_t before, uint32_t slot, uint32_t& child) {
-      if (!parked) return;
+    auto place = [&](bool has, unsigned long long m, uint32_t before, V3 o, V3 d, double weight, uint32_t& child) {
+      if (!has) return;
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       const uint32_t at = base + before + rank;
       if (at < B.cap_nodes) {
-        const ParkedChild& c = park[slot + threadIdx.x];
         WfNodeRay& r = B.rays[at - n_roots];
-        r.o[0] = c.o[0], r.o[1] = c.o[1], r.o[2] = c.o[2];
-        r.d[0] = c.d[0], r.d[1] = c.d[1], r.d[2] = c.d[2];
-        r.weight = c.weight;
+        r.o[0] = o.x, r.o[1] = o.y, r.o[2] = o.z;
+        r.d[0] = d.x, r.d[1] = d.y, r.d[2] = d.z;
+        r.weight = weight;
         r.depth = child_depth;
         r.reserved_ = 0;
         child = at;
@@ -93,9 +91,9 @@ struct ParkSink {
         B.ctrl[kCtrlOverflow] = 1u;
       }
     };
-    place(parked_refraction, m0, before0, 0u, child_refraction);
-    place(parked_reflection, m1, before1, kBlock, child_reflection);
-    __syncthreads();  // the parking slots and the counts are free again
+    place(has_refraction, m0, before0, o_refraction, d_refraction, weight_refraction, child_refraction);
+    place(has_reflection, m1, before1, o_reflection, d_reflection, weight_reflection, child_reflection);
+    __syncthreads();  // the counts are free again
   }
   __device__ __forceinline__ void store(WfNodeOut& out) const {
     out.t[0] = t.x, out.t[1] = t.y, out.t[2] = t.z;

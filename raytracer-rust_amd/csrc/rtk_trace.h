@@ -24,8 +24,8 @@ struct StackEntry {
 // Where a node's results go.  trace_step reports, in the order the iterative evaluation adds them to
 // the pixel: a miss (ambient * weight); for a hit, each child that may not be traced any more because
 // the depth limit is reached (ambient * its weight: refraction, then reflection), each child that is
-// to be traced (refraction, then reflection), and at the end the lit surface colour times the node's
-// weight.  StackSink is the depth-first evaluation by one lane: terms are added to the pixel's colour
+// to be traced (refraction, then reflection), children_done() once the node's children are all
+// reported (whether or not it has any), and at the end the lit surface colour times the node's weight.  StackSink is the depth-first evaluation by one lane: terms are added to the pixel's colour
 // as they come, children go on the lane's stack (so the reflected subtree is traced before the
 // refracted one).
 struct StackSink {
@@ -34,6 +34,7 @@ struct StackSink {
   V3& color;
   __device__ __forceinline__ void term(V3 v, double w) { color = color + v * w; }
   __device__ __forceinline__ void untraced_child(bool, V3 ambient, double w) { color = color + ambient * w; }
+  __device__ __forceinline__ void children_done() {}
   __device__ __forceinline__ void child(bool, V3 o, V3 d, double w, int depth) {
     StackEntry& e = stack[sp++];
     e.ox = o.x, e.oy = o.y, e.oz = o.z;
@@ -233,6 +234,7 @@ __device__ __forceinline__ void shade_hit(const DevScene& S, bool have, const No
     // children first, so that nothing of them stays live across the shadow sweep
     if (SECONDARY) emit_children(S, ob, g, h.n1, weight, depth, sink);
   }
+  sink.children_done();  // (every lane comes by here, with or without a hit)
 
 #if defined(RTK_NODE_CUT) && RTK_NODE_CUT >= 1  // experiment builds (wrong images): a node without its shadow rays
   const bool in_shadow = false;

@@ -61,11 +61,9 @@ __global__ void __launch_bounds__(kBlock, 4) wf_primary_kernel(DevScene S, DevCa
   const V3 origin = ld3(C.origin);
   const V3 dir = camera_ray_direction(C, x, y);
   WaveCount wc;
-  __shared__ ParkedChild s_park[2 * kBlock];
   __shared__ uint32_t s_counts[10];
-  ParkSink sink(s_park);
+  QueueSink sink(B, gridDim.x * kBlock, 1u, s_counts);
   trace_step<true, true, LB, WIDE, false, TRACK>(S, prim, prim_cluster, valid, true, origin, dir, 1.0, 0, sink, wc);
-  sink.flush(B, gridDim.x * kBlock, 1u, s_counts);
   sink.store(B.outs[blockIdx.x * kBlock + threadIdx.x]);
   flush_counts(counter_shard(B.counters), wc);
 }
@@ -117,7 +115,6 @@ template <int LB, bool WIDE, int SHADOWS>
 __global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_shade_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
   const uint32_t end = B.ctrl[kCtrlLevelEnd + level];
   WaveCount wc;
-  __shared__ ParkedChild s_park[2 * kBlock];
   __shared__ uint32_t s_counts[10];
   // workgroups take 256 nodes at a time, dealt round-robin, one lane per node, and queue the children of the 256 together
   const uint32_t begin = B.ctrl[kCtrlLevelEnd + level - 1];
@@ -135,9 +132,8 @@ __global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_shade_kernel(DevScene S
       const WfNodeHit& in = *reinterpret_cast<const WfNodeHit*>(&B.outs[i]);
       h.t = in.t, h.n1 = in.n1, h.obj = in.obj;
     }
-    ParkSink sink(s_park);
-    if (__any(have)) shade_hit<true, LB, WIDE, false, SHADOWS>(S, have, h, ro, rd, weight, (int)level, sink, wc);
-    sink.flush(B, n_roots, level + 1u, s_counts);
+    QueueSink sink(B, n_roots, level + 1u, s_counts);
+    shade_hit<true, LB, WIDE, false, SHADOWS>(S, have, h, ro, rd, weight, (int)level, sink, wc);  // (barriers inside: every wavefront goes in)
     if (have) sink.store(B.outs[i]);
   }
   flush_counts(counter_shard(B.counters), wc);

@@ -573,6 +573,9 @@ __device__ __forceinline__ void grid_march(const DevScene& S, bool active, V3 o,
 #if defined(RTK_HIT_CUT) && RTK_HIT_CUT == 2  // ... only the first cell
   budget = 0;
 #endif
+#if defined(RTK_HIT_BUDGET)  // ... at most that many cells
+  budget = RTK_HIT_BUDGET;
+#endif
   if (alive) enter_cell();
   [[maybe_unused]] int stat_rounds = 0;
   for (;;) {

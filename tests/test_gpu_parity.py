@@ -547,6 +547,88 @@ def test_large_scene_with_secondary_rays(rtk, dev, oracle):
         assert c.stats.rays_secondary > w * h
 
 
+def _glass_field(rtk, rng, n, r_lo, r_hi, extent, lights, affine=False, indices=(1.0,)):
+    """A volume of spheres (not a layer), a third of them glass with refractive indices from `indices`, over a
+    reflective floor: reflected and refracted rays cross many cells of the grid they walk, in every direction."""
+    M = rtk.Matrix4x4
+    scene = rtk.Scene()
+    for pos in lights:
+        scene.add_light(rtk.PointLight(pos, rtk.rgb(*(1.0 / len(lights),) * 3)))
+    mat = rtk.Material.default()
+    scene.add_object(rtk.Plane().with_material(mat.with_pattern(rtk.Texture.checker(rtk.WHITE, rtk.BLACK)).with_reflective(0.5)))
+    for i in range(n):
+        r = float(np.exp(rng.uniform(np.log(r_lo), np.log(r_hi))))
+        c = (rng.uniform(-extent, extent), rng.uniform(r, 0.8 * extent), rng.uniform(0.0, 2 * extent))
+        t = M.translate(*c)
+        if affine and i % 3 == 1:
+            t = t * M.rotate_y(rng.uniform(0, 6.28)) * M.rotate_x(rng.uniform(0, 6.28)) * M.scale(r * rng.uniform(0.3, 1.0), r * rng.uniform(0.3, 1.0), r)
+        else:
+            t = t * M.scale(r, r, r)
+        m = mat.with_color(rtk.rgb(*rng.uniform(0.2, 1.0, size=3)))
+        if i % 3 == 0:
+            m = m.with_transparency(0.9).with_reflective(0.8).with_ambient(0.1).with_diffuse(0.2).with_refractivity(
+                float(indices[i // 3 % len(indices)]))
+        scene.add_object(rtk.Sphere().with_material(m).with_transform(t))
+    return scene
+
+
+GRID_CASES = ["equal indices", "different indices", "affine spheres", "point lights", "point and w = 0 lights",
+              "radii over three decades", "far from the origin"]
+
+
+@pytest.mark.parametrize("case", GRID_CASES)
+def test_secondary_rays_through_the_cell_grid(rtk, dev, oracle, case):
+    """Reflected and refracted rays walk the scene's cell grid lane by lane (forward for the closest hit,
+    backward for the entry before it when refractive indices differ); shadow rays of their hits towards lights
+    built from points walk it too.  Both trace orders against the oracle, pixels and ray counts."""
+    rng = np.random.default_rng(11 + GRID_CASES.index(case))
+    M = rtk.Matrix4x4
+    extent = 12.0
+    w0 = [rtk.vec3(-8, 30, -12), rtk.vec3(10, 25, -5), rtk.vec3(2, 40, 6)]
+    w1 = [rtk.point(-8, 30, -12), rtk.point(10, 25, -5), rtk.point(0.0, 3.0, 9.0)]  # the last one inside the field
+    kw = dict(n=500, r_lo=0.3, r_hi=1.2, extent=extent, lights=w0)
+    if case == "different indices":
+        kw["indices"] = (1.0, 1.33, 1.5, 2.4)
+    elif case == "affine spheres":
+        kw.update(affine=True, indices=(1.0, 1.5))
+    elif case == "point lights":
+        kw.update(lights=w1, indices=(1.0, 1.5))
+    elif case == "point and w = 0 lights":
+        kw["lights"] = [w1[0], w0[1], w1[2]]
+    elif case == "radii over three decades":  # lists too long for small cells: the grid's cells grow, or the scene keeps its sweeps
+        kw.update(n=700, r_lo=0.004, r_hi=4.0)
+    scene = _glass_field(rtk, rng, **kw)
+    camera = _field_camera(rtk, extent, 144, 81)
+    if case == "far from the origin":
+        shift = M.translate(3000.0, -200.0, 7000.0)
+        for node in scene.nodes:
+            node.transform = shift * node.transform
+        camera.transform = camera.transform * M.translate(-3000.0, 200.0, -7000.0)
+    for order in (rtk.abi.RTK_TRACE_BY_LEVEL, rtk.abi.RTK_TRACE_DEPTH_FIRST):
+        dev.set_trace_order(order, 1 << 22)
+        c = check_against_oracle(dev, oracle, scene, camera, f"cell grid, {case}, order {order}")
+        assert c.stats.rays_secondary > 144 * 81 // 2
+    dev.set_trace_order(rtk.abi.RTK_TRACE_AUTO, 64 << 20)
+
+
+def test_secondary_rays_that_start_far_outside_the_grid(rtk, dev, oracle):
+    """A mirror floor seen to the horizon and a mirror wall 40,000 units away: reflected rays start up to
+    thousands of grid sizes away from the spheres; those beyond a hundred take the cluster sweep, the others
+    enter the grid through its side (the walk starts where the f64 slab test puts it)."""
+    rng = np.random.default_rng(5)
+    M = rtk.Matrix4x4
+    scene = _glass_field(rtk, rng, 300, 0.3, 1.0, 8.0, [rtk.vec3(-8, 30, -12), rtk.point(5, 20, 0)])
+    mirror = rtk.Material.default().with_color(rtk.rgb(0.9, 0.9, 1.0)).with_reflective(0.9).with_diffuse(0.1)
+    scene.nodes[0].material = mirror  # the floor
+    scene.add_object(rtk.Plane().with_material(mirror).with_transform(M.translate(0, 0, 40000.0) * M.rotate_x(math.pi / 2)))
+    camera = rtk.Camera(160, 90, rtk.PI / 2.5)
+    camera.transform = M.look_at(rtk.point(0, 1.5, -30), rtk.point(0, 1.0, 10), rtk.vec3(0, 1, 0))
+    for order in (rtk.abi.RTK_TRACE_BY_LEVEL, rtk.abi.RTK_TRACE_DEPTH_FIRST):
+        dev.set_trace_order(order, 1 << 22)
+        check_against_oracle(dev, oracle, scene, camera, f"origins far outside the grid, order {order}")
+    dev.set_trace_order(rtk.abi.RTK_TRACE_AUTO, 64 << 20)
+
+
 def test_random_rays_in_a_large_scene(rtk, dev, oracle):
     """`Scene::trace` for 2048 unrelated rays through 600 spheres (w = 0 and w = 1 lights)."""
     scene = rtk.synthetic.make_scene(600, True, 2, 99, glass=True)

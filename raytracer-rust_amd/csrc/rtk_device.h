@@ -87,13 +87,20 @@ struct DevLight {
 // (The shadow of a sphere widens away from the light -- the reference's shadow ray has a w
 // component, src/scene.rs:208-225 -- so the lists are built for points with (p - centre).g >= h_min,
 // where every shading point on a sphere lies; points below take the cluster sweeps.)
+// The lists are built from geometry -- discs a little larger (1e-4 relative, 1e-5 of the scene absolute)
+// than the spheres' shadows.  The reference's f64 quadratic, evaluated for a point at distance D, carries
+// a rounding error of some 1e-15 D^2 in its discriminant and so reports roots for lines that miss a sphere
+// by up to that much (squared): geometry stops being a superset of "the reference finds a root" once
+// that exceeds the discs' extra size, at D of about a hundred scene sizes.  Points further away than
+// that take the cluster sweeps too, whose FP32 slack grows with the point's distance.
 struct LightGrid {
   float e1[3], e2[3];        // orthonormal basis of the plane perpendicular to g
   float h_min;
   float u0, v0, inv_cell;    // cell (i, j) covers u0 + [i, i+1) / inv_cell, v0 + [j, j+1) / inv_cell
   uint32_t nx, ny;
   uint32_t cell_base;        // first cell of this light in DevScene::grid_cells
-  uint32_t reserved_[3];
+  float d_max2;              // squared distance from DevScene::center up to which the lists are supersets (below)
+  uint32_t reserved_[2];
 };
 static_assert(sizeof(LightGrid) == 64, "one light grid header is 64 bytes");
 

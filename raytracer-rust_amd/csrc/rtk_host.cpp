@@ -519,6 +519,10 @@ static bool build_light_grids(const SphereKey* keys, uint32_t n_sph, const doubl
     G.h_min = round_up(h_min + margin);  // the device's (p - centre).g is off by far less than the margin
     G.u0 = u0f, G.v0 = v0f, G.inv_cell = inv;
     G.nx = nx, G.ny = ny;
+    // the discs are 1e-5 (1 + scale) larger than the shadows: enough against the rounding of the reference's
+    // discriminant, about 64 x 2^-53 x D^2, up to D = 1e-5 (1 + scale) / 8.4e-8; 100 (1 + scale) to be safe
+    const double d_max = 100.0 * (1.0 + scale);
+    G.d_max2 = (float)std::fmin(d_max * d_max, 1.0e37);
     pl.ok = true;
   };
   HostPool::get().run(n_lights, [&](uint32_t k) {

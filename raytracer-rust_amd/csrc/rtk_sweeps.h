@@ -336,10 +336,11 @@ __device__ __forceinline__ bool shadow_by_grids(const DevScene& S, bool active, 
   const float px = (float)pc.x, py = (float)pc.y, pz = (float)pc.z;
   bool in_range = active;
   float rho_max = 0.0f;
+  const float pp = __builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px));
   for (uint32_t k = 0; k < S.n_lights; ++k) {
     const float4 lf = S.light_filter[k];
     const float h = __builtin_fmaf(pz, lf.z, __builtin_fmaf(py, lf.y, px * lf.x));
-    in_range = in_range && h >= S.light_grid[k].h_min;
+    in_range = in_range && h >= S.light_grid[k].h_min && pp <= S.light_grid[k].d_max2;
     rho_max = fmaxf(rho_max, fabsf(lf.w) * 1.0001f);
   }
 #if defined(RTK_SHADOW_CUT) && RTK_SHADOW_CUT == 1  // experiment builds (wrong images): no point takes the cluster sweeps
@@ -484,8 +485,8 @@ __device__ __forceinline__ void closest_general(const DevScene& S, bool active, 
 // of a cell boundary; and the f64 roots of a sphere far less than the margin away from its ball.  So a
 // sphere with a root in the stretch of the ray walked so far is listed in one of the cells visited,
 // and a walk may end once the current cell's far side lies 0.05 cells behind the best root.  Rays
-// that start further from the grid than 100 times its size, or whose direction has no usable length,
-// do not take the walk: the caller sweeps them.
+// that start further from the grid than 200,000 cells, or whose direction has no usable length, do not
+// take the walk: the caller sweeps them.
 //
 // Lanes whose filter kept a sphere wait with it until 24 of them do, or until no lane has anything
 // else to do: the f64 test then runs for all of them at once instead of once per lane and candidate.
@@ -497,7 +498,8 @@ template <typename ExactFn>
 __device__ __forceinline__ void grid_march(const DevScene& S, bool active, V3 o, V3 d, bool backward, double t_stop,
                                            WaveCount& wc, ExactFn&& exact) {
   const double dd = dot3(d, d);
-  const double rs = __builtin_amdgcn_rsq(dd);  // relative error about 1e-8: the walk needs a direction, not the direction
+  double rs = __builtin_amdgcn_rsq(dd);
+  rs = rs * __builtin_fma(-0.5 * dd, rs * rs, 1.5);  // one Newton step: a ray that enters the grid from 200,000 cells away must still enter it at the right place
   const double sign = backward ? -1.0 : 1.0;
   const double len_h = dd * rs * S.tg_inv_h;   // ray parameter -> cell units
   const double oc[3] = {(o.x - S.tg_lo[0]) * S.tg_inv_h, (o.y - S.tg_lo[1]) * S.tg_inv_h, (o.z - S.tg_lo[2]) * S.tg_inv_h};
@@ -642,8 +644,9 @@ __device__ __forceinline__ void grid_march(const DevScene& S, bool active, V3 o,
 // May this lane's ray take the walk?  (Comparisons are written so that a NaN says no.)
 __device__ __forceinline__ bool grid_walk_applies(const DevScene& S, V3 o, V3 d) {
   const double dd = dot3(d, d);
-  const double n_max = (double)max(S.tg_n[0], max(S.tg_n[1], S.tg_n[2]));
-  const double reach = 100.0 * n_max;
+  // 200,000 cells: the roots of a ray that grazes a sphere of ten cells' radius from that far are off by
+  // 1.5e-8 x distance x radius / cell = 0.03 cells at most, inside what the walk allows for when it stops
+  const double reach = 2.0e5;
   bool ok = dd > 1.0e-280 && dd < 1.0e280;
   ok = ok && fabs((o.x - S.tg_lo[0]) * S.tg_inv_h) <= reach && fabs((o.y - S.tg_lo[1]) * S.tg_inv_h) <= reach &&
        fabs((o.z - S.tg_lo[2]) * S.tg_inv_h) <= reach;
@@ -675,7 +678,11 @@ __device__ __forceinline__ void closest_secondary(const DevScene& S, bool active
   }
   // forward for the winner; then, where the winner's material asks for n1, backward for the entry before it
 #pragma unroll 1
+#if defined(RTK_HIT_CUT) && RTK_HIT_CUT == 4  // experiment builds (wrong images): no walk against the direction
+  for (int pass = 0; pass < 1; ++pass) {
+#else
   for (int pass = 0; pass < (TRACK ? 2 : 1); ++pass) {
+#endif
     bool go = walks;
     if (pass == 1) {
       go = walks && best.obj != 0xffffffffu;

@@ -204,6 +204,9 @@ __device__ __forceinline__ NodeHit find_hit(const DevScene& S, const float4* __r
     if (h.obj != 0xffffffffu) {
       const RTK_RO DevObject& ob = S.objects[h.obj];
       if (!is_approx_zero(ob.reflectivity) || !is_approx_zero(ob.transparency)) {
+#if defined(RTK_WALK_STATS) && RTK_WALK_STATS == 4  // experiment build: exact_tests counts the rays that take the literal evaluation
+        wc.exact += lanes_where(graze);
+#endif
         if (graze)
           h.n1 = literal_n1(S, ro, rd, h.obj, best.t);
         else if (best.prev_obj != 0xffffffffu)

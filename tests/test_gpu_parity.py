@@ -612,15 +612,18 @@ def test_secondary_rays_through_the_cell_grid(rtk, dev, oracle, case):
 
 
 def test_secondary_rays_that_start_far_outside_the_grid(rtk, dev, oracle):
-    """A mirror floor seen to the horizon and a mirror wall 40,000 units away: reflected rays start up to
-    thousands of grid sizes away from the spheres; those beyond a hundred take the cluster sweep, the others
-    enter the grid through its side (the walk starts where the f64 slab test puts it)."""
+    """A mirror floor seen to the horizon and mirror walls 40,000 and 300,000 units away: reflected rays start
+    up to hundreds of thousands of cells away from the spheres; those beyond 200,000 cells take the cluster sweep,
+    the others enter the grid through its side (the walk starts where the f64 slab test puts it).  (Not further:
+    seen from a million scene sizes away, the reference's own discriminants are rounding noise -- their terms
+    cancel to less than 2^-53 of their size -- and which spheres then "block" a light is decided by that noise.)"""
     rng = np.random.default_rng(5)
     M = rtk.Matrix4x4
     scene = _glass_field(rtk, rng, 300, 0.3, 1.0, 8.0, [rtk.vec3(-8, 30, -12), rtk.point(5, 20, 0)])
     mirror = rtk.Material.default().with_color(rtk.rgb(0.9, 0.9, 1.0)).with_reflective(0.9).with_diffuse(0.1)
     scene.nodes[0].material = mirror  # the floor
     scene.add_object(rtk.Plane().with_material(mirror).with_transform(M.translate(0, 0, 40000.0) * M.rotate_x(math.pi / 2)))
+    scene.add_object(rtk.Plane().with_material(mirror).with_transform(M.translate(-3.0e5, 0, 0) * M.rotate_z(math.pi / 2)))
     camera = rtk.Camera(160, 90, rtk.PI / 2.5)
     camera.transform = M.look_at(rtk.point(0, 1.5, -30), rtk.point(0, 1.0, 10), rtk.vec3(0, 1, 0))
     for order in (rtk.abi.RTK_TRACE_BY_LEVEL, rtk.abi.RTK_TRACE_DEPTH_FIRST):

@@ -18,9 +18,13 @@ for name in names:
     if name == "C1":
         scene = rtk.PackedScene.from_yaml_file(os.path.join(ROOT, "tests/golden/test01.yaml")).build()
         camera = rtk.Camera(1920, 1080, rtk.PI / 3)
-    elif name in ("C3g", "C4g", "C3gw1", "C4gw1"):  # the glass variant of a big configuration at 1080p: secondary rays
+    elif name in ("C3g", "C4g", "C3gw1", "C4gw1", "C3gt", "C4gt"):  # the glass variant of a big configuration at 1080p: secondary rays
         n = 1000 if name.startswith("C3g") else 10000
         scene = rtk.synthetic.make_scene(n, True, 4, 0xC0FFEE00 + n, glass=True)
+        if name.endswith("t"):  # ... with refractive indices that differ: the kernels keep the entry before the winner
+            for i, node in enumerate(scene.nodes):
+                if node.material.transparency > 0:
+                    node.material.refractivity = 1.5 if i % 2 else 1.33
         if name.endswith("w1"):  # ... with lights built from points
             scene.lights = [rtk.PointLight(rtk.point(*l.position[:3]), l.intensity) for l in scene.lights]
         camera = rtk.synthetic.make_camera(n, *size)

@@ -43,7 +43,7 @@ hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevC
 const unsigned int* wavefront_overflow_flag(const WavefrontBuffers& B);
 // Level 0 of that order on the bundle tests of the opaque path (rtk_opaque.hip), for the scenes it
 // applies to: the camera rays of tiles [tile_base, tile_base + n_tiles) of T, records and children into B.
-bool queue_primary_bundled_applies(const DevScene& S);
+bool queue_primary_bundled_applies(const DevScene& S, const DevCamera& C);
 hipError_t launch_queue_primary_bundled(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
                                         const float4* prim_ball, const float4* prim_cluster, const RenderTarget& T,
                                         uint32_t tile_base, uint32_t n_tiles, const WavefrontBuffers& B);

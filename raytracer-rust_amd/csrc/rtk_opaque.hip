@@ -154,7 +154,9 @@ template <typename StashT = Stash>
 __device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera& C, const float4* __restrict__ prim,
                                               const float4* __restrict__ prim_ball,
                                               const float4* __restrict__ prim_cluster, const PixelRef& px, Closest& best,
-                                              WaveCount& wc, StashT* stash = nullptr) {
+                                              WaveCount& wc, StashT* stash = nullptr, bool track = false, bool* graze = nullptr) {
+  // track: the entry before the winner is kept as well (scenes whose refractive indices differ), and *graze
+  // is set when a sphere has both roots within 1e-5 of each other on the ray (trace_step's rule)
   const V3 origin = ld3(C.origin);
   const uint32_t lane = threadIdx.x & 63u;
   closest_init(best);
@@ -166,7 +168,7 @@ __device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera
     for (uint32_t ip = 0; ip < S.n_planes; ++ip) {
       const uint32_t obj = S.plane_object[ip];
       double t0, t1;
-      if (px.valid && intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) closest_consider(best, t0, obj, false);
+      if (px.valid && intersect_object(S.objects[obj], origin, d, 0.0, t0, t1)) closest_consider(best, t0, obj, track);
     }
   }
   if (!wave_any(px.valid)) return;
@@ -202,8 +204,9 @@ __device__ __forceinline__ void primary_phase(const DevScene& S, const DevCamera
             double t0, t1;
             const V3 d = stash ? get3(stash->dir) : camera_ray_direction(C, launder(px.x), px.y);
             if (intersect_sphere_record(S, rec, origin, d, 0.0, t0, t1)) {
-              closest_consider(best, t0, rec.object, false);
-              closest_consider(best, t1, rec.object, false);
+              closest_consider(best, t0, rec.object, track);
+              closest_consider(best, t1, rec.object, track);
+              if (track && fabs(t0 - t1) < 0.00001) *graze = true;
             }
           }
         }
@@ -847,13 +850,16 @@ __global__ void __launch_bounds__(64, 5) render_uniform_kernel(DevScene S, DevCa
 // the camera rays of the pass's tiles, their shadow rays and their shading exactly as above, but
 // the pixel is not stored -- what the camera ray's node adds to it goes to the node's record, and the
 // reflected and refracted children of the hit are queued.  For scenes whose lights all have w = 0
-// and whose refractive indices are all equal (n1 = 1 on every camera ray); one workgroup per tile,
-// node = workgroup * 256 + thread.
+// (one workgroup per tile, node = workgroup * 256 + thread).  TRACK: the scene's refractive indices differ,
+// so a camera ray that hits a reflecting or transmitting surface needs n1, the material of the entry before
+// the winner on its line -- something BEHIND the camera, which the cone tests never look at: those lanes walk
+// the scene's cell grid from the camera against the ray's direction (grid_march), and a ray on which some
+// sphere has both roots within 1e-5 of each other takes the literal evaluation, as in find_hit.
 #ifndef RTK_QP_OCC
 #define RTK_QP_OCC 5
 #endif
-template <int KW>
-__global__ void __launch_bounds__(kBlock, RTK_QP_OCC) queue_primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
+template <int KW, bool TRACK>
+__global__ void __launch_bounds__(kBlock, TRACK ? 4 : RTK_QP_OCC) queue_primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                                  const float4* __restrict__ prim_ball,
                                                                  const float4* __restrict__ prim_cluster, RenderTarget T,
                                                                  uint32_t tile_base, WavefrontBuffers B) {
@@ -863,9 +869,38 @@ __global__ void __launch_bounds__(kBlock, RTK_QP_OCC) queue_primary_kernel(DevSc
   Closest best;
   WaveCount wc;
   wc.primary = lanes_where(px.valid);
-  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, wc, &stash);
+  bool graze = false;
+  primary_phase(S, C, prim, prim_ball, prim_cluster, px, best, wc, &stash, TRACK, &graze);
   const uint32_t obj = px.valid ? best.obj : 0xffffffffu;
   const bool hit = obj != 0xffffffffu;
+  double n1 = 1.0;
+  if constexpr (TRACK) {
+    bool need = false;
+    if (hit) {
+      const RTK_RO DevObject& ob = S.objects[obj];
+      need = !is_approx_zero(ob.reflectivity) || !is_approx_zero(ob.transparency);
+    }
+    if (__any(need)) {
+      const V3 o = ld3(C.origin), d = get3(stash.dir);
+      auto exact = [&](uint32_t at) -> double {
+        const RTK_RO SphRecord& rec = S.sph_record[at];
+        double t0, t1;
+        if (intersect_sphere_record(S, rec, o, d, 0.0, t0, t1)) {
+          closest_consider(best, t0, rec.object, true);
+          closest_consider(best, t1, rec.object, true);
+          if (fabs(t0 - t1) < 0.00001) graze = true;
+        }
+        return -best.prev_t;
+      };
+      grid_march(S, need, o, d, true, -best.prev_t, wc, exact);
+      if (need) {
+        if (graze)
+          n1 = literal_n1(S, o, d, obj, best.t);
+        else if (best.prev_obj != 0xffffffffu)
+          n1 = S.objects[best.prev_obj].refractivity;
+      }
+    }
+  }
   QueueSink sink(B, gridDim.x * kBlock, 1u, s_counts);
   V3 p = {0, 0, 0};
   if (hit) {
@@ -874,7 +909,7 @@ __global__ void __launch_bounds__(kBlock, RTK_QP_OCC) queue_primary_kernel(DevSc
     put3(stash.over, g.over);
     put3(stash.normal, g.normal);
     p = g.over;
-    emit_children(S, ob, g, 1.0, 1.0, 0, sink);  // children first: nothing of them stays live across the shadow phase
+    emit_children(S, ob, g, n1, 1.0, 0, sink);  // children first: nothing of them stays live across the shadow phase
   }
   sink.children_done();
   const bool in_shadow = shadow_phase_uniform<KW>(S, hit, p, wc);
@@ -888,12 +923,24 @@ __global__ void __launch_bounds__(kBlock, RTK_QP_OCC) queue_primary_kernel(DevSc
   flush_counts(counter_shard(B.counters), wc);
 }
 
-bool queue_primary_bundled_applies(const DevScene& S) { return S.lights_uniform && !S.track_n1 && S.max_depth >= 2; }
+// Scenes whose lights all have w = 0; where refractive indices differ, the scene must have its cell grid and the
+// camera must stand where a walk can start (grid_walk_applies: within 200,000 cells of the grid; half of that here).
+bool queue_primary_bundled_applies(const DevScene& S, const DevCamera& C) {
+  if (!S.lights_uniform || S.max_depth < 2) return false;
+  if (!S.track_n1) return true;
+  if (!S.trace_grid) return false;
+  for (int a = 0; a < 3; ++a)
+    if (!(std::fabs((C.origin[a] - S.tg_lo[a]) * S.tg_inv_h) <= 1.0e5)) return false;
+  return true;
+}
 
 hipError_t launch_queue_primary_bundled(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
                                         const float4* prim_ball, const float4* prim_cluster, const RenderTarget& T,
                                         uint32_t tile_base, uint32_t n_tiles, const WavefrontBuffers& B) {
-  hipLaunchKernelGGL((queue_primary_kernel<4>), dim3(n_tiles), dim3(kBlock), 0, st, S, C, prim, prim_ball, prim_cluster, T, tile_base, B);
+  if (S.track_n1)
+    hipLaunchKernelGGL((queue_primary_kernel<4, true>), dim3(n_tiles), dim3(kBlock), 0, st, S, C, prim, prim_ball, prim_cluster, T, tile_base, B);
+  else
+    hipLaunchKernelGGL((queue_primary_kernel<4, false>), dim3(n_tiles), dim3(kBlock), 0, st, S, C, prim, prim_ball, prim_cluster, T, tile_base, B);
   return hipGetLastError();
 }
 

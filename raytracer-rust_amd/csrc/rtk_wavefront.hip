@@ -249,7 +249,7 @@ hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevC
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const dim3 grid(n_tiles);
     // the camera level: on the opaque path's bundle tests where they apply, else through trace_step
-    if (queue_primary_bundled_applies(S))
+    if (queue_primary_bundled_applies(S, C))
       e = launch_queue_primary_bundled(st, S, C, prim, prim_ball, prim_cluster, T, tile_base, n_tiles, B);
     else
       e = track ? launch_primary_lb<true, true>(lb, grid, st, S, C, T, prim, prim_cluster, tile_base, B)

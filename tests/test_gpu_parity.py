@@ -573,7 +573,7 @@ def _glass_field(rtk, rng, n, r_lo, r_hi, extent, lights, affine=False, indices=
 
 
 GRID_CASES = ["equal indices", "different indices", "affine spheres", "point lights", "point and w = 0 lights",
-              "radii over three decades", "far from the origin"]
+              "radii over three decades", "far from the origin", "camera among the spheres", "camera inside a glass sphere"]
 
 
 @pytest.mark.parametrize("case", GRID_CASES)
@@ -599,6 +599,16 @@ def test_secondary_rays_through_the_cell_grid(rtk, dev, oracle, case):
         kw.update(n=700, r_lo=0.004, r_hi=4.0)
     scene = _glass_field(rtk, rng, **kw)
     camera = _field_camera(rtk, extent, 144, 81)
+    if case == "camera among the spheres":  # spheres behind the camera: the entry before a camera ray's hit (n1) lies there
+        kw["indices"] = (1.2, 1.5, 2.0)
+        scene = _glass_field(rtk, rng, **kw)
+        camera = _field_camera(rtk, extent, 144, 81, eye=rtk.point(0.3, 4.0, 11.0), to=rtk.point(2.0, 2.0, 20.0))
+    if case == "camera inside a glass sphere":
+        kw["indices"] = (1.2, 1.5, 2.0)
+        scene = _glass_field(rtk, rng, **kw)
+        glass = rtk.Material.default().with_transparency(0.9).with_reflective(0.5).with_diffuse(0.1).with_refractivity(1.7)
+        scene.add_object(rtk.Sphere().with_material(glass).with_transform(M.translate(0.0, 5.0, -4.0) * M.scale(2.5, 2.5, 2.5)))
+        camera = _field_camera(rtk, extent, 144, 81, eye=rtk.point(0.2, 5.3, -4.4), to=rtk.point(0.0, 3.0, 12.0))
     if case == "far from the origin":
         shift = M.translate(3000.0, -200.0, 7000.0)
         for node in scene.nodes:

@@ -850,7 +850,7 @@ __global__ void __launch_bounds__(64, 5) render_uniform_kernel(DevScene S, DevCa
 // the camera rays of the pass's tiles, their shadow rays and their shading exactly as above, but
 // the pixel is not stored -- what the camera ray's node adds to it goes to the node's record, and the
 // reflected and refracted children of the hit are queued.  For scenes whose lights all have w = 0
-// (one workgroup per tile, node = workgroup * 256 + thread).  TRACK: the scene's refractive indices differ,
+// (TABULATED) or w = 0 or 1, as for the fused kernel; one workgroup per tile, node = workgroup * 256 + thread.  TRACK: the scene's refractive indices differ,
 // so a camera ray that hits a reflecting or transmitting surface needs n1, the material of the entry before
 // the winner on its line -- something BEHIND the camera, which the cone tests never look at: those lanes walk
 // the scene's cell grid from the camera against the ray's direction (grid_march), and a ray on which some
@@ -858,7 +858,7 @@ __global__ void __launch_bounds__(64, 5) render_uniform_kernel(DevScene S, DevCa
 #ifndef RTK_QP_OCC
 #define RTK_QP_OCC 5
 #endif
-template <int KW, bool TRACK>
+template <int KW, bool TRACK, bool TABULATED>
 __global__ void __launch_bounds__(kBlock, TRACK ? 4 : RTK_QP_OCC) queue_primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                                  const float4* __restrict__ prim_ball,
                                                                  const float4* __restrict__ prim_cluster, RenderTarget T,
@@ -912,7 +912,7 @@ __global__ void __launch_bounds__(kBlock, TRACK ? 4 : RTK_QP_OCC) queue_primary_
     emit_children(S, ob, g, n1, 1.0, 0, sink);  // children first: nothing of them stays live across the shadow phase
   }
   sink.children_done();
-  const bool in_shadow = shadow_phase_uniform<KW>(S, hit, p, wc);
+  const bool in_shadow = TABULATED ? shadow_phase_uniform<KW>(S, hit, p, wc) : shadow_phase_bundled<KW>(S, hit, p, wc);
   if (px.valid) {
     if (hit)
       sink.term(shade_hit_stashed(S, launder(obj), in_shadow, &stash), 1.0);
@@ -923,10 +923,10 @@ __global__ void __launch_bounds__(kBlock, TRACK ? 4 : RTK_QP_OCC) queue_primary_
   flush_counts(counter_shard(B.counters), wc);
 }
 
-// Scenes whose lights all have w = 0; where refractive indices differ, the scene must have its cell grid and the
+// Scenes whose lights all have w = 0 or 1; where refractive indices differ, the scene must have its cell grid and the
 // camera must stand where a walk can start (grid_walk_applies: within 200,000 cells of the grid; half of that here).
 bool queue_primary_bundled_applies(const DevScene& S, const DevCamera& C) {
-  if (!S.lights_uniform || S.max_depth < 2) return false;
+  if (!(S.lights_uniform || S.lights_bundled) || S.max_depth < 2) return false;
   if (!S.track_n1) return true;
   if (!S.trace_grid) return false;
   for (int a = 0; a < 3; ++a)
@@ -937,10 +937,15 @@ bool queue_primary_bundled_applies(const DevScene& S, const DevCamera& C) {
 hipError_t launch_queue_primary_bundled(hipStream_t st, const DevScene& S, const DevCamera& C, const float4* prim,
                                         const float4* prim_ball, const float4* prim_cluster, const RenderTarget& T,
                                         uint32_t tile_base, uint32_t n_tiles, const WavefrontBuffers& B) {
-  if (S.track_n1)
-    hipLaunchKernelGGL((queue_primary_kernel<4, true>), dim3(n_tiles), dim3(kBlock), 0, st, S, C, prim, prim_ball, prim_cluster, T, tile_base, B);
+  const dim3 grid(n_tiles), block(kBlock);
+  if (S.track_n1 && S.lights_uniform)
+    hipLaunchKernelGGL((queue_primary_kernel<4, true, true>), grid, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, tile_base, B);
+  else if (S.track_n1)
+    hipLaunchKernelGGL((queue_primary_kernel<4, true, false>), grid, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, tile_base, B);
+  else if (S.lights_uniform)
+    hipLaunchKernelGGL((queue_primary_kernel<4, false, true>), grid, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, tile_base, B);
   else
-    hipLaunchKernelGGL((queue_primary_kernel<4, false>), dim3(n_tiles), dim3(kBlock), 0, st, S, C, prim, prim_ball, prim_cluster, T, tile_base, B);
+    hipLaunchKernelGGL((queue_primary_kernel<4, false, false>), grid, block, 0, st, S, C, prim, prim_ball, prim_cluster, T, tile_base, B);
   return hipGetLastError();
 }
 

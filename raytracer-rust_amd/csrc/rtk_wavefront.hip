@@ -34,6 +34,9 @@ namespace rtk {
 #ifndef RTK_WF_GRID_MAX
 #define RTK_WF_GRID_MAX 65536u
 #endif
+#ifndef RTK_WF_HIT_BLOCK
+#define RTK_WF_HIT_BLOCK 64  // workgroups of one wavefront: nothing in that kernel is shared, and a wavefront slot that falls free is taken at once
+#endif
 #ifndef RTK_WF_HIT_OCC
 #define RTK_WF_HIT_OCC 4
 #endif
@@ -81,7 +84,7 @@ struct WfNodeHit {  // what the first launch leaves at the start of a node's WfN
 static_assert(sizeof(WfNodeHit) <= sizeof(WfNodeOut), "a node's hit lies inside its result record");
 
 template <bool WIDE, bool TRACK>
-__global__ void __launch_bounds__(kBlock, RTK_WF_HIT_OCC) wf_hit_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
+__global__ void __launch_bounds__(RTK_WF_HIT_BLOCK, RTK_WF_HIT_OCC) wf_hit_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
   // the level ends where the queue ends now: nothing is queued while this kernel runs.  The kernel that
   // shades the level queues the next one's nodes as it goes, so the end is written down for it.
   const uint32_t end = min(B.ctrl[kCtrlNodes], B.cap_nodes);
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(kBlock, RTK_WF_HIT_OCC) wf_hit_kernel(DevScene
   // counter in memory costs more than the uneven shares it avoids: one address takes an atomic every
   // 12 ns or so, and a level has tens of thousands of wavefronts' worth of nodes.)
   const uint32_t begin = B.ctrl[kCtrlLevelEnd + level - 1];
-  const uint32_t n_waves = gridDim.x * (kBlock / 64u), wave = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6);
+  const uint32_t n_waves = gridDim.x * (RTK_WF_HIT_BLOCK / 64u), wave = blockIdx.x * (RTK_WF_HIT_BLOCK / 64u) + (threadIdx.x >> 6);
   for (uint32_t first = begin + wave * 64u; first < end; first += n_waves * 64u) {
     const uint32_t i = first + lane;
     const bool have = i < end;
@@ -260,12 +263,12 @@ hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevC
     // One workgroup per tile of the pass: a level usually has fewer nodes than the pass has pixels, so most
     // workgroups take one run of 256 nodes (or none) and the hardware's dispatcher evens out what the nodes
     // cost; a level with more nodes than that gives every workgroup several runs.
-    const dim3 level_grid(std::min<uint32_t>(RTK_WF_GRID_MAX, n_tiles)), hit_grid = level_grid;
+    const dim3 level_grid(std::min<uint32_t>(RTK_WF_GRID_MAX, n_tiles)), hit_grid(level_grid.x * (kBlock / RTK_WF_HIT_BLOCK));
     for (uint32_t level = 1; level < S.max_depth; ++level) {
       if (track)
-        hipLaunchKernelGGL((wf_hit_kernel<true, true>), hit_grid, dim3(kBlock), 0, st, S, level, n_roots, B);
+        hipLaunchKernelGGL((wf_hit_kernel<true, true>), hit_grid, dim3(RTK_WF_HIT_BLOCK), 0, st, S, level, n_roots, B);
       else
-        hipLaunchKernelGGL((wf_hit_kernel<true, false>), hit_grid, dim3(kBlock), 0, st, S, level, n_roots, B);
+        hipLaunchKernelGGL((wf_hit_kernel<true, false>), hit_grid, dim3(RTK_WF_HIT_BLOCK), 0, st, S, level, n_roots, B);
       if ((e = hipGetLastError()) != hipSuccess) return e;
       switch (shadow_mode(S)) {
         case kShadowGrids: e = launch_shade_lb<true, kShadowGrids>(lb, level_grid, st, S, level, n_roots, B); break;

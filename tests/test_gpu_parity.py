@@ -621,6 +621,32 @@ def test_secondary_rays_through_the_cell_grid(rtk, dev, oracle, case):
     dev.set_trace_order(rtk.abi.RTK_TRACE_AUTO, 64 << 20)
 
 
+@pytest.mark.parametrize("case", ["100,000 spheres in a volume", "100,000 spheres, point lights", "40 spheres in one place",
+                                  "33 spheres (the smallest scene with a grid)"])
+def test_cell_grid_sizes(rtk, dev, oracle, case):
+    """The grid at its limits: a volume of 100,000 spheres (cells capped per axis, lists of several entries), all
+    spheres in one cell, and the smallest scene that gets a grid; both trace orders."""
+    n, extent, seed = {"1": (100000, 60.0, 1), "4": (40, 5.0, 3), "3": (33, 5.0, 4)}[case[0]]
+    seed += case.endswith("point lights")
+    rng = np.random.default_rng(seed)
+    lights = [rtk.vec3(-50, 200, -80), rtk.vec3(80, 150, 20)]
+    if case.endswith("point lights"):
+        lights = [rtk.point(-50, 200, -80), rtk.point(10, 30, 40)]
+    scene = _glass_field(rtk, rng, n, 0.2 if n > 1000 else 0.4, 0.8 if n > 1000 else 1.0, extent, lights, indices=(1.0, 1.5))
+    if case.startswith("40"):
+        M = rtk.Matrix4x4
+        for i, node in enumerate(scene.nodes[1:]):
+            r = node.transform.e[0]
+            node.transform = M.translate(0.0, 1.5 + 1e-9 * i, 5.0) * M.scale(r, r, r)
+    w, h = (48, 27) if n > 1000 else (96, 54)
+    camera = _field_camera(rtk, extent, w, h)
+    for order in (rtk.abi.RTK_TRACE_BY_LEVEL, rtk.abi.RTK_TRACE_DEPTH_FIRST):
+        dev.set_trace_order(order, 1 << 22)
+        c = check_against_oracle(dev, oracle, scene, camera, f"{case}, order {order}")
+        assert c.stats.rays_secondary > w * h // 2
+    dev.set_trace_order(rtk.abi.RTK_TRACE_AUTO, 64 << 20)
+
+
 def test_secondary_rays_that_start_far_outside_the_grid(rtk, dev, oracle):
     """A mirror floor seen to the horizon and mirror walls 40,000 and 300,000 units away: reflected rays start
     up to hundreds of thousands of cells away from the spheres; those beyond 200,000 cells take the cluster sweep,

@@ -191,11 +191,11 @@ bool wavefront_applies(const DevScene& S) { return S.any_secondary && S.n_object
 // ... and launches small enough for the depth-first kernel's last pixels to matter.  That kernel
 // spends a fixed time on its slowest pixels (a wavefront stays for as long as its deepest ray tree
 // takes) and then less per pixel than the queue does, which moves a few hundred bytes per node through
-// memory; from some launch size on it is the faster one.  Measured on glass scenes of 10,000 / 1,000 /
-// 64 spheres: the queue wins at 2 Mpixel by 24 % / 23 % / -, is level at 8.3 Mpixel with 10,000
-// spheres (5.31 against 5.41 ms) and behind there with 1,000 (4.68 against 4.49 ms) and with 64.
+// memory; from some launch size on it is the faster one.  Measured on glass scenes, by level / depth
+// first in ms: 10,000 spheres 1080p 1.46 / 2.17, 4K 4.51 / 5.36, 5K 8.05 / 8.50, 8K (in passes) 16.5 / 17.2;
+// 1,000 spheres 4K 3.96 / 4.28, 5K 7.40 / 6.87, 8K 14.9 / 14.0; 64 spheres 1080p 0.98 / 1.13, 4K 3.18 / 2.62.
 bool wavefront_pays(const DevScene& S, uint64_t launch_pixels) {
-  return launch_pixels <= (S.n_spheres >= 4096u ? 10000000ull : 5000000ull);
+  return launch_pixels <= (S.n_spheres >= 4096u ? 64000000ull : S.n_spheres >= 256u ? 10000000ull : 4000000ull);
 }
 
 namespace {

@@ -482,7 +482,7 @@ __device__ __forceinline__ void closest_general(const DevScene& S, bool active, 
 // cell plus 1e-5 of the grid's size, reaches into the cell (rtk_scene_upload).  The walk starts from
 // a point of the ray computed in f64 and keeps positions in cell units (at most 256 per axis), so the
 // cells it visits differ from those of the exact ray only where the ray passes within about 1e-4 cells
-// of a cell boundary; and the f64 roots of a sphere far less than the margin away from its ball.  So a
+// of a cell boundary; and the f64 roots of a sphere lie far less than the margin away from its ball.  So a
 // sphere with a root in the stretch of the ray walked so far is listed in one of the cells visited,
 // and a walk may end once the current cell's far side lies 0.05 cells behind the best root.  Rays
 // that start further from the grid than 200,000 cells, or whose direction has no usable length, do not

@@ -445,6 +445,9 @@ static int frame_launch(Frame& f, const rtk::Partition& p, float* d_rgb_f32, uin
   t.band_rows = p.band_rows, t.band_period = p.band_period, t.band_offset = p.band_offset, t.row0 = p.row0;
   rtk_context* ctx = f.ctx;
   if (f.capturing) split = false;
+  // rays and shading in one kernel: its end is the frame's end, and a third event per frame is a packet the
+  // stream can do without
+  if (f.opaque && f.scene->dev.max_depth > 0 && (f.scene->dev.lights_uniform || f.scene->dev.lights_bundled)) split = false;
   if (f.opaque) {
     if (split) ctx->ev_split[f.slot] = true;
     RTK_HIP(rtk::launch_render_opaque(f.st, f.scene->dev, f.cam, f.scr.prim, f.scr.prim_ball, f.scr.prim_cluster, t,

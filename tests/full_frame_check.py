@@ -2,6 +2,10 @@
 CPU oracle, band by band (a 10,000-sphere 4K frame is minutes of oracle time on 16 threads).
 
     python tests/full_frame_check.py [C4] [bands]
+
+C3g / C4g: the 1,000- / 10,000-sphere scene with a quarter of the spheres glass and a mirror floor at 1920x1080
+(secondary rays through the cell grid); a trailing t gives the glass refractive indices of 1.33 and 1.5, a
+trailing w1 rebuilds the lights from points.
 """
 import importlib, os, sys, time
 import numpy as np
@@ -14,7 +18,18 @@ import oracle_binding as oracle
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C4"
 bands = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-scene, camera = rtk.synthetic.config(name)
+if name[:3] in ("C3g", "C4g"):
+    n = 1000 if name.startswith("C3g") else 10000
+    scene = rtk.synthetic.make_scene(n, True, 4, 0xC0FFEE00 + n, glass=True)
+    if name.endswith("t"):
+        for i, node in enumerate(scene.nodes):
+            if node.material.transparency > 0:
+                node.material.refractivity = 1.5 if i % 2 else 1.33
+    if name.endswith("w1"):
+        scene.lights = [rtk.PointLight(rtk.point(*l.position[:3]), l.intensity) for l in scene.lights]
+    camera = rtk.synthetic.make_camera(n, 1920, 1080)
+else:
+    scene, camera = rtk.synthetic.config(name)
 dev = device.Device(0)
 canvas = dev.render(scene, camera)
 w, h = camera.width, camera.height

@@ -545,6 +545,11 @@ static bool build_light_grids(const SphereKey* keys, uint32_t n_sph, const doubl
   }
   out.filter.resize(out.entries.size());
   for (size_t i = 0; i < out.entries.size(); ++i) out.filter[i] = records[out.entries[i]];
+  if (std::getenv("RTK_GRID_STATS"))  // a diagnostic: what the grids came to
+    for (const rtk::LightGrid& G : out.header)
+      std::fprintf(stderr, "rtk: light grid %u x %u cells of %.4g, h_min %.4g\n", G.nx, G.ny, 1.0 / (double)G.inv_cell, (double)G.h_min);
+  if (std::getenv("RTK_GRID_STATS"))
+    std::fprintf(stderr, "rtk: light grids: %zu cells, %zu entries for %u spheres\n", out.cells.size(), out.entries.size(), n_sph);
   return true;
 }
 
@@ -662,6 +667,8 @@ static bool build_trace_grid(const SphereKey* keys, uint32_t n_sph, const double
     }
     for (int a = 0; a < 3; ++a) out.lo[a] = g_lo[a], out.n[a] = n[a];
     out.inv_h = inv_h;
+    if (std::getenv("RTK_GRID_STATS"))  // a diagnostic: what the grid came to
+      std::fprintf(stderr, "rtk: cell grid %u x %u x %u cells of %.4g, %zu entries for %u spheres\n", n[0], n[1], n[2], h, total, n_sph);
     return true;
   }
   return false;

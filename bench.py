@@ -172,8 +172,15 @@ def main():
         if world > 1:
             tdist.barrier()
 
+    # An idle MI355X needs about 30 back-to-back frames (15 ms of load) before its clock has settled: frames
+    # 0-9 of a run average 0.62 ms, 10-19 0.52, 20-29 0.50, every later ten 0.489 (tools/ramp_probe.py).  So
+    # that a short run (--steps 20 --warmup 5) also reads the steady state, the GPU is kept busy with untimed
+    # frames of the same workload until 64 have gone by, then come the W warm-up frames and the K timed ones.
+    settle = max(0, 64 - warmup)
+
     def timed(run):
-        """W untimed frames, then exactly K timed ones between barriers; the slowest rank's time."""
+        """Settling frames and W warm-up frames, all untimed, then exactly K timed ones between barriers; the slowest rank's time."""
+        run(settle)
         run(warmup)
         sync_all()
         t0 = time.perf_counter()
@@ -320,6 +327,7 @@ def main():
             "n_gpus": n_gpus,
             "steps": steps,
             "warmup": warmup,
+            "settle_frames": settle,  # untimed frames before the warm-up that bring an idle GPU's clock up (see timed())
             "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",

@@ -149,7 +149,7 @@ int rtk_set_trace_order(rtk_context* ctx, uint32_t order, uint64_t max_queue_nod
     rtk::WavefrontBuffers& w = ctx->wavefront;
     if (w.rays) (void)hipFree(w.rays);
     if (w.outs) (void)hipFree(w.outs);
-    w.rays = nullptr, w.outs = nullptr, w.cap_nodes = 0;
+    w.rays = nullptr, w.outs = nullptr, w.cuts = nullptr, w.cap_nodes = 0;
     w.nodes_per_pixel = rtk::kWavefrontNodesPerPixel;
     ctx->wavefront_max_nodes = (uint32_t)max_queue_nodes;
   }
@@ -372,11 +372,11 @@ static const rtk::WavefrontBuffers* context_wavefront(rtk_context* ctx, size_t p
   // context that went from 4K frames to thumbnails gives the memory back)
   if (w.cap_nodes >= want && w.cap_nodes / 8u <= want) return &w;
   // never more than an eighth of the device memory that is free now: larger launches run in passes
-  // (128 bytes per node: a 1080p launch asks for 1.6 GB, a 4K launch for 6.4 GB, the cap is 8 GB)
+  // (112 bytes per node: a 1080p launch asks for 1.4 GB, a 4K launch for 5.6 GB, the cap is 7 GB)
   size_t free_bytes = 0, total_bytes = 0;
   if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
-    const size_t held = (size_t)w.cap_nodes * (sizeof(rtk::WfNodeRay) + sizeof(rtk::WfNodeOut));
-    want = std::min(want, (free_bytes + held) / 8u / (sizeof(rtk::WfNodeRay) + sizeof(rtk::WfNodeOut)));
+    const size_t held = (size_t)w.cap_nodes * rtk::kWavefrontNodeBytes;
+    want = std::min(want, (free_bytes + held) / 8u / rtk::kWavefrontNodeBytes);
     if (want < floor_nodes) return nullptr;
     if (w.cap_nodes >= want && w.cap_nodes / 8u <= want) return &w;
   } else {
@@ -386,16 +386,17 @@ static const rtk::WavefrontBuffers* context_wavefront(rtk_context* ctx, size_t p
   if (hipDeviceSynchronize() != hipSuccess) return nullptr;
   if (w.rays) (void)hipFree(w.rays);
   if (w.outs) (void)hipFree(w.outs);
-  w.rays = nullptr, w.outs = nullptr, w.cap_nodes = 0;
+  w.rays = nullptr, w.outs = nullptr, w.cuts = nullptr, w.cap_nodes = 0;
   if (!w.ctrl && hipMalloc((void**)&w.ctrl, sizeof(unsigned int) * rtk::kWavefrontCtrlWords) != hipSuccess) w.ctrl = nullptr;
   if (!w.counters && hipMalloc((void**)&w.counters, sizeof(rtk::DevCounters) * rtk::kCounterShards) != hipSuccess) w.counters = nullptr;
   if (!w.ctrl || !w.counters || hipMalloc((void**)&w.rays, want * sizeof(rtk::WfNodeRay)) != hipSuccess ||
-      hipMalloc((void**)&w.outs, want * sizeof(rtk::WfNodeOut)) != hipSuccess) {
+      hipMalloc((void**)&w.outs, want * (sizeof(rtk::WfNodeOut) + sizeof(rtk::WfNodeCut))) != hipSuccess) {
     (void)hipGetLastError();
     if (w.rays) (void)hipFree(w.rays);
-    w.rays = nullptr, w.outs = nullptr;
+    w.rays = nullptr, w.outs = nullptr, w.cuts = nullptr;
     return nullptr;
   }
+  w.cuts = reinterpret_cast<rtk::WfNodeCut*>(w.outs + want);
   w.cap_nodes = (uint32_t)want;
   return &w;
 }

@@ -196,18 +196,22 @@ struct WfNodeRay {
   double weight;
   uint32_t depth, reserved_;
 };
-struct WfNodeOut {
-  double t[3];                                // the node's own term (flag bit 0)
-  double w_refraction, w_reflection;          // weights of children cut off by the depth limit (flag bits 1, 2)
-  uint32_t child_refraction, child_reflection;  // node indices, 0xffffffff: none
-  uint32_t flags, reserved_[3];
+struct WfNodeOut {                              // what the final walk over a pixel's tree reads of a node: half a line
+  double t[3];                                  // the node's own term; zero when it has none (a sum that started at +0 is never
+                                                // -0, so adding +0 changes nothing)
+  uint32_t child_refraction, child_reflection;  // node indices; 0xffffffff: none; 0xfffffffe: cut off by the depth limit, weight in cuts[]
 };
-static_assert(sizeof(WfNodeRay) == 64 && sizeof(WfNodeOut) == 64, "node records are one 64-byte line each");
+struct WfNodeCut {                              // beside it, read only where a child index says so
+  double w_refraction, w_reflection;            // weights of the children cut off by the depth limit
+};
+static_assert(sizeof(WfNodeRay) == 64 && sizeof(WfNodeOut) == 32 && sizeof(WfNodeCut) == 16, "node records: a line, half a line, a quarter");
+constexpr size_t kWavefrontNodeBytes = sizeof(WfNodeRay) + sizeof(WfNodeOut) + sizeof(WfNodeCut);  // device memory per queue node
 constexpr uint32_t kWavefrontCtrlWords = 16;        // nodes so far, overflow flag, one level end per depth
 constexpr uint32_t kWavefrontNodesPerPixel = 6;     // queue room a pass reserves per pixel (its camera ray included), to begin with
 struct WavefrontBuffers {
   WfNodeRay* rays = nullptr;    // cap_nodes entries
   WfNodeOut* outs = nullptr;    // cap_nodes entries
+  WfNodeCut* cuts = nullptr;    // cap_nodes entries, behind outs in the same allocation
   unsigned int* ctrl = nullptr;  // kWavefrontCtrlWords words
   DevCounters* counters = nullptr;  // kCounterShards shards: the launch's own ray counts
   unsigned int* host_overflow = nullptr;  // page-locked host word, set when a launch ran out of queue room

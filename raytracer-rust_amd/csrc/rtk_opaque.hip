@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(kBlock, TRACK ? 4 : RTK_QP_OCC) queue_primary_
       }
     }
   }
-  QueueSink sink(B, gridDim.x * kBlock, 1u, s_counts);
+  QueueSink sink(S, B, gridDim.x * kBlock, 1u, s_counts);
   V3 p = {0, 0, 0};
   if (hit) {
     const RTK_RO DevObject& ob = S.objects[obj];
@@ -919,7 +919,7 @@ __global__ void __launch_bounds__(kBlock, TRACK ? 4 : RTK_QP_OCC) queue_primary_
     else
       sink.term(ld3(S.ambient), 1.0);  // trace_inner: miss -> ambient_color
   }
-  sink.store(B.outs[blockIdx.x * kBlock + threadIdx.x]);
+  sink.store(blockIdx.x * kBlock + threadIdx.x);
   flush_counts(counter_shard(B.counters), wc);
 }
 

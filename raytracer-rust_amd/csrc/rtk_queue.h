@@ -8,8 +8,8 @@
 
 namespace rtk {
 
-constexpr uint32_t kNoNode = 0xffffffffu;
-constexpr uint32_t kHasTerm = 1u, kUntracedRefraction = 2u, kUntracedReflection = 4u;
+constexpr uint32_t kNoNode = 0xffffffffu;  // a child index: no such child
+constexpr uint32_t kCutOff = 0xfffffffeu;  // ... a child cut off by the depth limit: it adds the scene's ambient colour times its weight
 
 // words of the control block
 constexpr int kCtrlNodes = 0;     // nodes handed out so far in this pass (camera rays included)
@@ -28,7 +28,7 @@ static_assert(kCtrlLevelEnd + kMaxDepth < (int)kWavefrontCtrlWords, "one level e
 struct QueueSink {
   V3 t = {0, 0, 0};
   double w_refraction = 0.0, w_reflection = 0.0;
-  uint32_t child_refraction = kNoNode, child_reflection = kNoNode, flags = 0;
+  uint32_t child_refraction = kNoNode, child_reflection = kNoNode;
   // the children, from sink.child() until children_done()
   V3 o_refraction = {0, 0, 0}, d_refraction = {0, 0, 0}, o_reflection = {0, 0, 0}, d_reflection = {0, 0, 0};
   double weight_refraction = 0.0, weight_reflection = 0.0;
@@ -36,18 +36,19 @@ struct QueueSink {
   const WavefrontBuffers& B;
   uint32_t n_roots, child_depth;
   uint32_t* s_counts;  // 10 words of LDS
+  bool ambient_black;  // the scene's ambient colour is zero: a cut-off child with a finite weight adds +-0, which changes no sum
 
-  __device__ __forceinline__ QueueSink(const WavefrontBuffers& buffers, uint32_t roots, uint32_t depth_of_children, uint32_t* lds_counts)
-      : B(buffers), n_roots(roots), child_depth(depth_of_children), s_counts(lds_counts) {}
-  __device__ __forceinline__ void term(V3 v, double w) {
-    t = v * w;
-    flags |= kHasTerm;
-  }
+  __device__ __forceinline__ QueueSink(const DevScene& S, const WavefrontBuffers& buffers, uint32_t roots, uint32_t depth_of_children,
+                                       uint32_t* lds_counts)
+      : B(buffers), n_roots(roots), child_depth(depth_of_children), s_counts(lds_counts),
+        ambient_black(S.ambient[0] == 0.0 && S.ambient[1] == 0.0 && S.ambient[2] == 0.0) {}
+  __device__ __forceinline__ void term(V3 v, double w) { t = v * w; }
   __device__ __forceinline__ void untraced_child(bool reflection, V3, double w) {
+    if (ambient_black && __builtin_isfinite(w)) return;  // (0 x inf and 0 x NaN are NaN: those are kept)
     if (reflection)
-      w_reflection = w, flags |= kUntracedReflection;
+      w_reflection = w, child_reflection = kCutOff;
     else
-      w_refraction = w, flags |= kUntracedRefraction;
+      w_refraction = w, child_refraction = kCutOff;
   }
   __device__ __forceinline__ void child(bool reflection, V3 o, V3 d, double w, int) {
     if (reflection)
@@ -95,13 +96,16 @@ struct QueueSink {
     place(has_reflection, m1, before1, o_reflection, d_reflection, weight_reflection, child_reflection);
     __syncthreads();  // the counts are free again
   }
-  __device__ __forceinline__ void store(WfNodeOut& out) const {
+  __device__ __forceinline__ void store(uint32_t node) const {
+    WfNodeOut& out = B.outs[node];
     out.t[0] = t.x, out.t[1] = t.y, out.t[2] = t.z;
-    out.w_refraction = w_refraction;
-    out.w_reflection = w_reflection;
     out.child_refraction = child_refraction;
     out.child_reflection = child_reflection;
-    out.flags = flags;
+    if (child_refraction == kCutOff || child_reflection == kCutOff) {
+      WfNodeCut& cut = B.cuts[node];
+      cut.w_refraction = w_refraction;
+      cut.w_reflection = w_reflection;
+    }
   }
 };
 

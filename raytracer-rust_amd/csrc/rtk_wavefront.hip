@@ -65,9 +65,9 @@ __global__ void __launch_bounds__(kBlock, 4) wf_primary_kernel(DevScene S, DevCa
   const V3 dir = camera_ray_direction(C, x, y);
   WaveCount wc;
   __shared__ uint32_t s_counts[10];
-  QueueSink sink(B, gridDim.x * kBlock, 1u, s_counts);
+  QueueSink sink(S, B, gridDim.x * kBlock, 1u, s_counts);
   trace_step<true, true, LB, WIDE, false, TRACK>(S, prim, prim_cluster, valid, true, origin, dir, 1.0, 0, sink, wc);
-  sink.store(B.outs[blockIdx.x * kBlock + threadIdx.x]);
+  sink.store(blockIdx.x * kBlock + threadIdx.x);
   flush_counts(counter_shard(B.counters), wc);
 }
 
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(kBlock, 4) wf_primary_kernel(DevScene S, DevCa
 // kernels because either half alone needs far fewer registers than both together: the first, whose lanes
 // spend their time waiting for the cells and lists of their walks, then has twice the wavefronts in
 // flight to wait with.
-struct WfNodeHit {  // what the first launch leaves at the start of a node's WfNodeOut
+struct WfNodeHit {  // what the first launch leaves in a node's WfNodeOut
   double t, n1;
   uint32_t obj, reserved_;
 };
@@ -135,9 +135,9 @@ __global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_shade_kernel(DevScene S
       const WfNodeHit& in = *reinterpret_cast<const WfNodeHit*>(&B.outs[i]);
       h.t = in.t, h.n1 = in.n1, h.obj = in.obj;
     }
-    QueueSink sink(B, n_roots, level + 1u, s_counts);
+    QueueSink sink(S, B, n_roots, level + 1u, s_counts);
     shade_hit<true, LB, WIDE, false, SHADOWS>(S, have, h, ro, rd, weight, (int)level, sink, wc);  // (barriers inside: every wavefront goes in)
-    if (have) sink.store(B.outs[i]);
+    if (have) sink.store(i);
   }
   flush_counts(counter_shard(B.counters), wc);
 }
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_shade_kernel(DevScene S
 // of the one-lane evaluation (a node's untraced refraction and reflection, its own term, then the
 // reflected subtree, then the refracted one), and the framebuffer store (src/graphics.rs:44-46, 59-74).
 __global__ void __launch_bounds__(kBlock) wf_gather_kernel(DevScene S, DevCamera C, RenderTarget T, uint32_t tile_base,
-                                                           const WfNodeOut* __restrict__ outs) {
+                                                           const WfNodeOut* __restrict__ outs, const WfNodeCut* __restrict__ cuts) {
   __shared__ float s_rgb[768];
   __shared__ uint32_t s_px[256];
   const V3 ambient = ld3(S.ambient);
@@ -155,14 +155,14 @@ __global__ void __launch_bounds__(kBlock) wf_gather_kernel(DevScene S, DevCamera
   int sp = 0;
   pending[sp++] = blockIdx.x * kBlock + threadIdx.x;
   while (sp > 0) {
-    const WfNodeOut& n = outs[pending[--sp]];
-    const uint32_t flags = n.flags;
-    if (flags & kUntracedRefraction) color = color + ambient * n.w_refraction;
-    if (flags & kUntracedReflection) color = color + ambient * n.w_reflection;
-    if (flags & kHasTerm) color = color + V3{n.t[0], n.t[1], n.t[2]};
+    const uint32_t at = pending[--sp];
+    const WfNodeOut& n = outs[at];
     const uint32_t refraction = n.child_refraction, reflection = n.child_reflection;
-    if (refraction != kNoNode) pending[sp++] = refraction;
-    if (reflection != kNoNode) pending[sp++] = reflection;  // on top: walked first
+    if (refraction == kCutOff) color = color + ambient * cuts[at].w_refraction;
+    if (reflection == kCutOff) color = color + ambient * cuts[at].w_reflection;
+    color = color + V3{n.t[0], n.t[1], n.t[2]};
+    if (refraction < kCutOff) pending[sp++] = refraction;
+    if (reflection < kCutOff) pending[sp++] = reflection;  // on top: walked first
   }
   store_tile(C, T, tile_base + blockIdx.x, color, s_rgb, s_px);
 }
@@ -277,7 +277,7 @@ hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevC
       }
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(wf_gather_kernel, grid, dim3(kBlock), 0, st, S, C, T, tile_base, B.outs);
+    hipLaunchKernelGGL(wf_gather_kernel, grid, dim3(kBlock), 0, st, S, C, T, tile_base, B.outs, B.cuts);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   hipLaunchKernelGGL(wf_commit_kernel, dim3(1), dim3(kCounterShards), 0, st, B.ctrl, B.counters, counters, B.host_overflow);

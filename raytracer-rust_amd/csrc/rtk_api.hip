@@ -372,7 +372,7 @@ static const rtk::WavefrontBuffers* context_wavefront(rtk_context* ctx, size_t p
   // context that went from 4K frames to thumbnails gives the memory back)
   if (w.cap_nodes >= want && w.cap_nodes / 8u <= want) return &w;
   // never more than an eighth of the device memory that is free now: larger launches run in passes
-  // (112 bytes per node: a 1080p launch asks for 1.4 GB, a 4K launch for 5.6 GB, the cap is 7 GB)
+  // (124 bytes per node: a 1080p launch asks for 1.5 GB, a 4K launch for 6.2 GB, the cap is 7.8 GB)
   size_t free_bytes = 0, total_bytes = 0;
   if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
     const size_t held = (size_t)w.cap_nodes * rtk::kWavefrontNodeBytes;
@@ -389,7 +389,7 @@ static const rtk::WavefrontBuffers* context_wavefront(rtk_context* ctx, size_t p
   w.rays = nullptr, w.outs = nullptr, w.cuts = nullptr, w.cap_nodes = 0;
   if (!w.ctrl && hipMalloc((void**)&w.ctrl, sizeof(unsigned int) * rtk::kWavefrontCtrlWords) != hipSuccess) w.ctrl = nullptr;
   if (!w.counters && hipMalloc((void**)&w.counters, sizeof(rtk::DevCounters) * rtk::kCounterShards) != hipSuccess) w.counters = nullptr;
-  if (!w.ctrl || !w.counters || hipMalloc((void**)&w.rays, want * sizeof(rtk::WfNodeRay)) != hipSuccess ||
+  if (!w.ctrl || !w.counters || hipMalloc((void**)&w.rays, (want + 63u) / 64u * rtk::kRayBlockBytes) != hipSuccess ||
       hipMalloc((void**)&w.outs, want * (sizeof(rtk::WfNodeOut) + sizeof(rtk::WfNodeCut))) != hipSuccess) {
     (void)hipGetLastError();
     if (w.rays) (void)hipFree(w.rays);

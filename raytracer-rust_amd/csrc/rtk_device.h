@@ -189,13 +189,16 @@ __device__ __forceinline__ DevCounters* counter_shard(DevCounters* base) { retur
 
 // Level-by-level tracing of scenes with secondary rays (rtk_wavefront.hip): a queued ray, what
 // its node contributes, and the buffers of a context.  Node i of a pass is a camera ray for
-// i < n_roots (no queue entry: the ray is generated from the pixel), else the queue entry
-// rays[i - n_roots]; outs[i] is its result.
-struct WfNodeRay {
-  double o[3], d[3];
-  double weight;
-  uint32_t depth, reserved_;
-};
+// i < n_roots (no queue entry: the ray is generated from the pixel), else queue entry i - n_roots;
+// outs[i] is its result.
+// Queue entries lie in blocks of 64: within a block every field is a run of 64 values, so the 64 lanes of a
+// wavefront, which take consecutive entries, read and write whole cache lines per field and touch only the
+// fields they need.  Fields (f64): origin, direction, the factor with which the ray enters its pixel -- written
+// when the entry is queued; t and n1 of the closest hit, and (u32, last in the block) the object hit -- written by
+// the launch that finds the hits, read by the one that shades them; n1 only where refractive indices differ.
+constexpr uint32_t kRayOrigin = 0, kRayDirection = 3, kRayWeight = 6, kRayT = 7, kRayN1 = 8, kRayFields = 9;
+constexpr size_t kRayBlockBytes = 64 * (8 * kRayFields + 4);
+static_assert(kRayBlockBytes % 128 == 0, "blocks start on cache lines");
 struct WfNodeOut {                              // what the final walk over a pixel's tree reads of a node: half a line
   double t[3];                                  // the node's own term; zero when it has none (a sum that started at +0 is never
                                                 // -0, so adding +0 changes nothing)
@@ -204,12 +207,12 @@ struct WfNodeOut {                              // what the final walk over a pi
 struct WfNodeCut {                              // beside it, read only where a child index says so
   double w_refraction, w_reflection;            // weights of the children cut off by the depth limit
 };
-static_assert(sizeof(WfNodeRay) == 64 && sizeof(WfNodeOut) == 32 && sizeof(WfNodeCut) == 16, "node records: a line, half a line, a quarter");
-constexpr size_t kWavefrontNodeBytes = sizeof(WfNodeRay) + sizeof(WfNodeOut) + sizeof(WfNodeCut);  // device memory per queue node
+static_assert(sizeof(WfNodeOut) == 32 && sizeof(WfNodeCut) == 16, "result records: half a 64-byte line, a quarter");
+constexpr size_t kWavefrontNodeBytes = kRayBlockBytes / 64 + sizeof(WfNodeOut) + sizeof(WfNodeCut);  // device memory per queue node
 constexpr uint32_t kWavefrontCtrlWords = 16;        // nodes so far, overflow flag, one level end per depth
 constexpr uint32_t kWavefrontNodesPerPixel = 6;     // queue room a pass reserves per pixel (its camera ray included), to begin with
 struct WavefrontBuffers {
-  WfNodeRay* rays = nullptr;    // cap_nodes entries
+  unsigned char* rays = nullptr;  // cap_nodes entries in blocks of 64 (kRayBlockBytes each)
   WfNodeOut* outs = nullptr;    // cap_nodes entries
   WfNodeCut* cuts = nullptr;    // cap_nodes entries, behind outs in the same allocation
   unsigned int* ctrl = nullptr;  // kWavefrontCtrlWords words

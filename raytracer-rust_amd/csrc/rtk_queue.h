@@ -17,6 +17,14 @@ constexpr int kCtrlOverflow = 1;  // some child found no room: the launch is to 
 constexpr int kCtrlLevelEnd = 3;  // [kCtrlLevelEnd + l]: one past the last node of level l (l <= kMaxDepth)
 static_assert(kCtrlLevelEnd + kMaxDepth < (int)kWavefrontCtrlWords, "one level end per depth fits the control block");
 
+// Queue entry j: its element of the block's first field (field f of the entry is [f * 64]), and of the object plane.
+__device__ __forceinline__ double* ray_fields(const WavefrontBuffers& B, uint32_t j) {
+  return reinterpret_cast<double*>(B.rays + (size_t)(j >> 6) * kRayBlockBytes) + (j & 63u);
+}
+__device__ __forceinline__ uint32_t* ray_object(const WavefrontBuffers& B, uint32_t j) {
+  return reinterpret_cast<uint32_t*>(B.rays + (size_t)(j >> 6) * kRayBlockBytes + 64u * 8u * kRayFields) + (j & 63u);
+}
+
 // Result sink for one node of the level-by-level order: keeps the node's terms and queues its
 // children.  The workgroups of these kernels move in step (one node per lane, then all together): when
 // every lane has formed the children of its hit (children_done, which every thread of the workgroup
@@ -81,12 +89,10 @@ struct QueueSink {
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       const uint32_t at = base + before + rank;
       if (at < B.cap_nodes) {
-        WfNodeRay& r = B.rays[at - n_roots];
-        r.o[0] = o.x, r.o[1] = o.y, r.o[2] = o.z;
-        r.d[0] = d.x, r.d[1] = d.y, r.d[2] = d.z;
-        r.weight = weight;
-        r.depth = child_depth;
-        r.reserved_ = 0;
+        double* r = ray_fields(B, at - n_roots);
+        r[(kRayOrigin + 0) * 64] = o.x, r[(kRayOrigin + 1) * 64] = o.y, r[(kRayOrigin + 2) * 64] = o.z;
+        r[(kRayDirection + 0) * 64] = d.x, r[(kRayDirection + 1) * 64] = d.y, r[(kRayDirection + 2) * 64] = d.z;
+        r[kRayWeight * 64] = weight;
         child = at;
       } else {
         B.ctrl[kCtrlOverflow] = 1u;

@@ -72,17 +72,11 @@ __global__ void __launch_bounds__(kBlock, 4) wf_primary_kernel(DevScene S, DevCa
 }
 
 // Level l >= 1: the nodes queued by level l - 1 (all of depth l), one lane per node, in two launches.
-// The first finds every node's closest hit (and n1) and leaves it in the node's result record; the
-// second shades the hits, queues the children and overwrites the record with the node's terms.  Two
+// The first finds every node's closest hit (and n1) and leaves it beside the node's ray in the queue; the
+// second shades the hits, queues the children and writes the node's result record.  Two
 // kernels because either half alone needs far fewer registers than both together: the first, whose lanes
 // spend their time waiting for the cells and lists of their walks, then has twice the wavefronts in
 // flight to wait with.
-struct WfNodeHit {  // what the first launch leaves in a node's WfNodeOut
-  double t, n1;
-  uint32_t obj, reserved_;
-};
-static_assert(sizeof(WfNodeHit) <= sizeof(WfNodeOut), "a node's hit lies inside its result record");
-
 template <bool WIDE, bool TRACK>
 __global__ void __launch_bounds__(RTK_WF_HIT_BLOCK, RTK_WF_HIT_OCC) wf_hit_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
   // the level ends where the queue ends now: nothing is queued while this kernel runs.  The kernel that
@@ -100,15 +94,16 @@ __global__ void __launch_bounds__(RTK_WF_HIT_BLOCK, RTK_WF_HIT_OCC) wf_hit_kerne
     const uint32_t i = first + lane;
     const bool have = i < end;
     V3 ro = {0, 0, 0}, rd = {0, 0, 1};
+    double* r = ray_fields(B, i - n_roots);
     if (have) {
-      const WfNodeRay& r = B.rays[i - n_roots];
-      ro = {r.o[0], r.o[1], r.o[2]};
-      rd = {r.d[0], r.d[1], r.d[2]};
+      ro = {r[(kRayOrigin + 0) * 64], r[(kRayOrigin + 1) * 64], r[(kRayOrigin + 2) * 64]};
+      rd = {r[(kRayDirection + 0) * 64], r[(kRayDirection + 1) * 64], r[(kRayDirection + 2) * 64]};
     }
     const NodeHit h = find_hit<false, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, (int)level, wc);
     if (have) {
-      WfNodeHit& out = *reinterpret_cast<WfNodeHit*>(&B.outs[i]);
-      out.t = h.t, out.n1 = h.n1, out.obj = h.obj;
+      r[kRayT * 64] = h.t;
+      if (TRACK) r[kRayN1 * 64] = h.n1;
+      *ray_object(B, i - n_roots) = h.obj;
     }
   }
   flush_counts(counter_shard(B.counters), wc);
@@ -128,12 +123,13 @@ __global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_shade_kernel(DevScene S
     double weight = 0.0;
     NodeHit h = {0.0, 1.0, 0xffffffffu};
     if (have) {
-      const WfNodeRay& r = B.rays[i - n_roots];
-      ro = {r.o[0], r.o[1], r.o[2]};
-      rd = {r.d[0], r.d[1], r.d[2]};
-      weight = r.weight;
-      const WfNodeHit& in = *reinterpret_cast<const WfNodeHit*>(&B.outs[i]);
-      h.t = in.t, h.n1 = in.n1, h.obj = in.obj;
+      const double* r = ray_fields(B, i - n_roots);
+      ro = {r[(kRayOrigin + 0) * 64], r[(kRayOrigin + 1) * 64], r[(kRayOrigin + 2) * 64]};
+      rd = {r[(kRayDirection + 0) * 64], r[(kRayDirection + 1) * 64], r[(kRayDirection + 2) * 64]};
+      weight = r[kRayWeight * 64];
+      h.t = r[kRayT * 64];
+      if (S.track_n1) h.n1 = r[kRayN1 * 64];  // (1.0 in every other scene)
+      h.obj = *ray_object(B, i - n_roots);
     }
     QueueSink sink(S, B, n_roots, level + 1u, s_counts);
     shade_hit<true, LB, WIDE, false, SHADOWS>(S, have, h, ro, rd, weight, (int)level, sink, wc);  // (barriers inside: every wavefront goes in)

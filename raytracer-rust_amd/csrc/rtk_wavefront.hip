@@ -186,12 +186,13 @@ bool wavefront_applies(const DevScene& S) { return S.any_secondary && S.n_object
 
 // ... and launches small enough for the depth-first kernel's last pixels to matter.  That kernel
 // spends a fixed time on its slowest pixels (a wavefront stays for as long as its deepest ray tree
-// takes) and then less per pixel than the queue does, which moves a few hundred bytes per node through
-// memory; from some launch size on it is the faster one.  Measured on glass scenes, by level / depth
-// first in ms: 10,000 spheres 1080p 1.46 / 2.17, 4K 4.51 / 5.36, 5K 8.05 / 8.50, 8K (in passes) 16.5 / 17.2;
-// 1,000 spheres 4K 3.96 / 4.28, 5K 7.40 / 6.87, 8K 14.9 / 14.0; 64 spheres 1080p 0.98 / 1.13, 4K 3.18 / 2.62.
+// takes) and then less memory traffic per pixel than the queue, which moves about 250 bytes per node.
+// Measured on glass scenes, by level / depth first in ms: 10,000 spheres 1080p 1.28 / 2.17, 4K 3.78 / 5.40,
+// 5K 6.66 / 8.54, 8K (in passes) 13.5 / 17.3; 1,000 spheres 1080p 1.06 / 1.78, 4K 3.25 / 4.23, 5K 5.75 / 6.86,
+// 8K 11.8 / 14.0; 300 spheres 4K 2.46 / 3.14, 8K 9.24 / 10.8; 64 spheres 1080p 0.81 / 1.15, 4K 2.41 / 2.55,
+// 8K 9.19 / 8.57; 12 spheres 4K 1.53 / 1.80, 8K 5.79 / 6.45.
 bool wavefront_pays(const DevScene& S, uint64_t launch_pixels) {
-  return launch_pixels <= (S.n_spheres >= 4096u ? 64000000ull : S.n_spheres >= 256u ? 10000000ull : 4000000ull);
+  return launch_pixels <= (S.n_spheres >= 256u ? 64000000ull : 16000000ull);
 }
 
 namespace {

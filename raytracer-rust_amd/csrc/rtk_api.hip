@@ -372,7 +372,7 @@ static const rtk::WavefrontBuffers* context_wavefront(rtk_context* ctx, size_t p
   // context that went from 4K frames to thumbnails gives the memory back)
   if (w.cap_nodes >= want && w.cap_nodes / 8u <= want) return &w;
   // never more than an eighth of the device memory that is free now: larger launches run in passes
-  // (124 bytes per node: a 1080p launch asks for 1.5 GB, a 4K launch for 6.2 GB, the cap is 7.8 GB)
+  // (104 bytes per node: a 1080p launch asks for 1.3 GB, a 4K launch for 5.2 GB, the cap is 6.5 GB)
   size_t free_bytes = 0, total_bytes = 0;
   if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
     const size_t held = (size_t)w.cap_nodes * rtk::kWavefrontNodeBytes;

@@ -192,12 +192,10 @@ __device__ __forceinline__ DevCounters* counter_shard(DevCounters* base) { retur
 // i < n_roots (no queue entry: the ray is generated from the pixel), else queue entry i - n_roots;
 // outs[i] is its result.
 // Queue entries lie in blocks of 64: within a block every field is a run of 64 values, so the 64 lanes of a
-// wavefront, which take consecutive entries, read and write whole cache lines per field and touch only the
-// fields they need.  Fields (f64): origin, direction, the factor with which the ray enters its pixel -- written
-// when the entry is queued; t and n1 of the closest hit, and (u32, last in the block) the object hit -- written by
-// the launch that finds the hits, read by the one that shades them; n1 only where refractive indices differ.
-constexpr uint32_t kRayOrigin = 0, kRayDirection = 3, kRayWeight = 6, kRayT = 7, kRayN1 = 8, kRayFields = 9;
-constexpr size_t kRayBlockBytes = 64 * (8 * kRayFields + 4);
+// wavefront, which take consecutive entries, read and write whole cache lines per field.  Fields (f64): origin,
+// direction, the factor with which the ray enters its pixel.
+constexpr uint32_t kRayOrigin = 0, kRayDirection = 3, kRayWeight = 6, kRayFields = 7;
+constexpr size_t kRayBlockBytes = 64 * 8 * kRayFields;
 static_assert(kRayBlockBytes % 128 == 0, "blocks start on cache lines");
 struct WfNodeOut {                              // what the final walk over a pixel's tree reads of a node: half a line
   double t[3];                                  // the node's own term; zero when it has none (a sum that started at +0 is never

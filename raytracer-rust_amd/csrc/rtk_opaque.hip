@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(kBlock, TRACK ? 4 : RTK_QP_OCC) queue_primary_
       }
     }
   }
-  QueueSink sink(S, B, gridDim.x * kBlock, 1u, s_counts);
+  QueueSink sink(S, B, gridDim.x * kBlock, gridDim.x * kBlock, 1u, s_counts);
   V3 p = {0, 0, 0};
   if (hit) {
     const RTK_RO DevObject& ob = S.objects[obj];

@@ -12,17 +12,25 @@ constexpr uint32_t kNoNode = 0xffffffffu;  // a child index: no such child
 constexpr uint32_t kCutOff = 0xfffffffeu;  // ... a child cut off by the depth limit: it adds the scene's ambient colour times its weight
 
 // words of the control block
-constexpr int kCtrlNodes = 0;     // nodes handed out so far in this pass (camera rays included)
-constexpr int kCtrlOverflow = 1;  // some child found no room: the launch is to be rendered again
-constexpr int kCtrlLevelEnd = 3;  // [kCtrlLevelEnd + l]: one past the last node of level l (l <= kMaxDepth)
-static_assert(kCtrlLevelEnd + kMaxDepth < (int)kWavefrontCtrlWords, "one level end per depth fits the control block");
+constexpr int kCtrlOverflow = 1;    // some child found no room: the launch is to be rendered again
+constexpr int kCtrlLevelCount = 3;  // [kCtrlLevelCount + l]: nodes queued for level l of this pass (1 <= l <= kMaxDepth)
+static_assert(kCtrlLevelCount + kMaxDepth < (int)kWavefrontCtrlWords, "one count per depth fits the control block");
 
-// Queue entry j: its element of the block's first field (field f of the entry is [f * 64]), and of the object plane.
+// Where the nodes of level l lie in the pass's numbering: the camera rays are nodes 0 .. n_roots - 1, the levels
+// follow one another.  A level's count is final when the launch that shades the level before it has ended, so
+// the launch that traces level l reads its own bounds, and nothing has to mark them in between.
+struct LevelBounds {
+  uint32_t begin, end;  // not clamped to the queue's capacity: children placed at `end` onwards notice themselves when they do not fit
+};
+__device__ __forceinline__ LevelBounds level_bounds(const WavefrontBuffers& B, uint32_t n_roots, uint32_t level) {
+  uint32_t begin = n_roots;
+  for (uint32_t l = 1; l < level; ++l) begin += B.ctrl[kCtrlLevelCount + l];
+  return {begin, begin + B.ctrl[kCtrlLevelCount + level]};
+}
+
+// Queue entry j: its element of the block's first field (field f of the entry is [f * 64]).
 __device__ __forceinline__ double* ray_fields(const WavefrontBuffers& B, uint32_t j) {
   return reinterpret_cast<double*>(B.rays + (size_t)(j >> 6) * kRayBlockBytes) + (j & 63u);
-}
-__device__ __forceinline__ uint32_t* ray_object(const WavefrontBuffers& B, uint32_t j) {
-  return reinterpret_cast<uint32_t*>(B.rays + (size_t)(j >> 6) * kRayBlockBytes + 64u * 8u * kRayFields) + (j & 63u);
 }
 
 // Result sink for one node of the level-by-level order: keeps the node's terms and queues its
@@ -42,13 +50,13 @@ struct QueueSink {
   double weight_refraction = 0.0, weight_reflection = 0.0;
   bool has_refraction = false, has_reflection = false;
   const WavefrontBuffers& B;
-  uint32_t n_roots, child_depth;
+  uint32_t n_roots, child_base, child_depth;  // the children go to level child_depth, whose nodes start at child_base
   uint32_t* s_counts;  // 10 words of LDS
   bool ambient_black;  // the scene's ambient colour is zero: a cut-off child with a finite weight adds +-0, which changes no sum
 
-  __device__ __forceinline__ QueueSink(const DevScene& S, const WavefrontBuffers& buffers, uint32_t roots, uint32_t depth_of_children,
-                                       uint32_t* lds_counts)
-      : B(buffers), n_roots(roots), child_depth(depth_of_children), s_counts(lds_counts),
+  __device__ __forceinline__ QueueSink(const DevScene& S, const WavefrontBuffers& buffers, uint32_t roots, uint32_t first_child,
+                                       uint32_t depth_of_children, uint32_t* lds_counts)
+      : B(buffers), n_roots(roots), child_base(first_child), child_depth(depth_of_children), s_counts(lds_counts),
         ambient_black(S.ambient[0] == 0.0 && S.ambient[1] == 0.0 && S.ambient[2] == 0.0) {}
   __device__ __forceinline__ void term(V3 v, double w) { t = v * w; }
   __device__ __forceinline__ void untraced_child(bool reflection, V3, double w) {
@@ -75,7 +83,7 @@ struct QueueSink {
     if (threadIdx.x == 0) {
       uint32_t total = 0;
       for (int i = 0; i < 8; ++i) total += s_counts[i];
-      s_counts[8] = total ? atomicAdd(&B.ctrl[kCtrlNodes], total) : 0u;
+      s_counts[8] = total ? atomicAdd(&B.ctrl[kCtrlLevelCount + child_depth], total) : 0u;
     }
     __syncthreads();
     uint32_t before0 = 0, before1 = 0;  // children of the workgroup queued ahead of this wavefront's, per kind
@@ -83,7 +91,7 @@ struct QueueSink {
       before1 += s_counts[w];
       if (w < wave) before0 += s_counts[w], before1 += s_counts[4u + w];
     }
-    const uint32_t base = s_counts[8];
+    const uint32_t base = child_base + s_counts[8];
     auto place = [&](bool has, unsigned long long m, uint32_t before, V3 o, V3 d, double weight, uint32_t& child) {
       if (!has) return;
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));

@@ -34,18 +34,9 @@ namespace rtk {
 #ifndef RTK_WF_GRID_MAX
 #define RTK_WF_GRID_MAX 65536u
 #endif
-#ifndef RTK_WF_HIT_BLOCK
-#define RTK_WF_HIT_BLOCK 64  // workgroups of one wavefront: nothing in that kernel is shared, and a wavefront slot that falls free is taken at once
-#endif
-#ifndef RTK_WF_HIT_OCC
-#define RTK_WF_HIT_OCC 4
-#endif
-
-// Start of a pass: the camera rays of the pass are nodes 0 .. n_roots - 1, and level 0 ends behind them.
-__global__ void wf_mark_kernel(unsigned int* ctrl, uint32_t cap_nodes, uint32_t n_roots) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  ctrl[kCtrlNodes] = n_roots;
-  ctrl[kCtrlLevelEnd] = min(n_roots, cap_nodes);
+// Start of a pass: no level has nodes yet.
+__global__ void wf_mark_kernel(unsigned int* ctrl) {
+  if (blockIdx.x == 0 && threadIdx.x <= (unsigned)kMaxDepth) ctrl[kCtrlLevelCount + threadIdx.x] = 0u;
 }
 
 // Level 0: the camera rays of the pass's tiles (ray generation: src/scene/cameras.rs:52-69 with the
@@ -65,73 +56,39 @@ __global__ void __launch_bounds__(kBlock, 4) wf_primary_kernel(DevScene S, DevCa
   const V3 dir = camera_ray_direction(C, x, y);
   WaveCount wc;
   __shared__ uint32_t s_counts[10];
-  QueueSink sink(S, B, gridDim.x * kBlock, 1u, s_counts);
+  QueueSink sink(S, B, gridDim.x * kBlock, gridDim.x * kBlock, 1u, s_counts);
   trace_step<true, true, LB, WIDE, false, TRACK>(S, prim, prim_cluster, valid, true, origin, dir, 1.0, 0, sink, wc);
   sink.store(blockIdx.x * kBlock + threadIdx.x);
   flush_counts(counter_shard(B.counters), wc);
 }
 
-// Level l >= 1: the nodes queued by level l - 1 (all of depth l), one lane per node, in two launches.
-// The first finds every node's closest hit (and n1) and leaves it beside the node's ray in the queue; the
-// second shades the hits, queues the children and writes the node's result record.  Two
-// kernels because either half alone needs far fewer registers than both together: the first, whose lanes
-// spend their time waiting for the cells and lists of their walks, then has twice the wavefronts in
-// flight to wait with.
-template <bool WIDE, bool TRACK>
-__global__ void __launch_bounds__(RTK_WF_HIT_BLOCK, RTK_WF_HIT_OCC) wf_hit_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
-  // the level ends where the queue ends now: nothing is queued while this kernel runs.  The kernel that
-  // shades the level queues the next one's nodes as it goes, so the end is written down for it.
-  const uint32_t end = min(B.ctrl[kCtrlNodes], B.cap_nodes);
-  if (blockIdx.x == 0 && threadIdx.x == 0) B.ctrl[kCtrlLevelEnd + level] = end;
-  const uint32_t lane = threadIdx.x & 63u;
-  WaveCount wc;
-  // Wavefronts take the level's nodes 64 at a time, dealt round-robin.  (Handing them out through a
-  // counter in memory costs more than the uneven shares it avoids: one address takes an atomic every
-  // 12 ns or so, and a level has tens of thousands of wavefronts' worth of nodes.)
-  const uint32_t begin = B.ctrl[kCtrlLevelEnd + level - 1];
-  const uint32_t n_waves = gridDim.x * (RTK_WF_HIT_BLOCK / 64u), wave = blockIdx.x * (RTK_WF_HIT_BLOCK / 64u) + (threadIdx.x >> 6);
-  for (uint32_t first = begin + wave * 64u; first < end; first += n_waves * 64u) {
-    const uint32_t i = first + lane;
-    const bool have = i < end;
-    V3 ro = {0, 0, 0}, rd = {0, 0, 1};
-    double* r = ray_fields(B, i - n_roots);
-    if (have) {
-      ro = {r[(kRayOrigin + 0) * 64], r[(kRayOrigin + 1) * 64], r[(kRayOrigin + 2) * 64]};
-      rd = {r[(kRayDirection + 0) * 64], r[(kRayDirection + 1) * 64], r[(kRayDirection + 2) * 64]};
-    }
-    const NodeHit h = find_hit<false, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, (int)level, wc);
-    if (have) {
-      r[kRayT * 64] = h.t;
-      if (TRACK) r[kRayN1 * 64] = h.n1;
-      *ray_object(B, i - n_roots) = h.obj;
-    }
-  }
-  flush_counts(counter_shard(B.counters), wc);
-}
-
-template <int LB, bool WIDE, int SHADOWS>
-__global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_shade_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
-  const uint32_t end = B.ctrl[kCtrlLevelEnd + level];
+// Level l >= 1: the nodes queued by level l - 1 (all of depth l), one lane per node: closest hit, shading,
+// children to the queue, the node's result record.  One launch per level: the ray is read once and the hit
+// stays in registers.  (Two launches, one finding the hits and one shading them with the hit handed over
+// through the queue, gave the first twice the wavefronts in flight at half the registers; the 116 bytes per
+// node that cost weigh more: one launch is 1-7 % faster on every scene measured but one, 0.6 % slower.)
+// Workgroups take 256 nodes at a time, dealt round-robin, and queue the children of the 256 together.
+// (Handing nodes out through a counter in memory costs more than the uneven shares it avoids: one address
+// takes an atomic every 12 ns or so, and a level has tens of thousands of wavefronts' worth of nodes.)
+template <int LB, bool WIDE, bool TRACK, int SHADOWS>
+__global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_level_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
+  const LevelBounds lv = level_bounds(B, n_roots, level);
+  const uint32_t end = min(lv.end, B.cap_nodes);
   WaveCount wc;
   __shared__ uint32_t s_counts[10];
-  // workgroups take 256 nodes at a time, dealt round-robin, one lane per node, and queue the children of the 256 together
-  const uint32_t begin = B.ctrl[kCtrlLevelEnd + level - 1];
-  for (uint32_t base = begin + blockIdx.x * kBlock; base < end; base += gridDim.x * kBlock) {
+  for (uint32_t base = lv.begin + blockIdx.x * kBlock; base < end; base += gridDim.x * kBlock) {
     const uint32_t i = base + threadIdx.x;
     const bool have = i < end;
     V3 ro = {0, 0, 0}, rd = {0, 0, 1};
     double weight = 0.0;
-    NodeHit h = {0.0, 1.0, 0xffffffffu};
     if (have) {
       const double* r = ray_fields(B, i - n_roots);
       ro = {r[(kRayOrigin + 0) * 64], r[(kRayOrigin + 1) * 64], r[(kRayOrigin + 2) * 64]};
       rd = {r[(kRayDirection + 0) * 64], r[(kRayDirection + 1) * 64], r[(kRayDirection + 2) * 64]};
       weight = r[kRayWeight * 64];
-      h.t = r[kRayT * 64];
-      if (S.track_n1) h.n1 = r[kRayN1 * 64];  // (1.0 in every other scene)
-      h.obj = *ray_object(B, i - n_roots);
     }
-    QueueSink sink(S, B, n_roots, level + 1u, s_counts);
+    const NodeHit h = find_hit<false, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, (int)level, wc);
+    QueueSink sink(S, B, n_roots, lv.end, level + 1u, s_counts);
     shade_hit<true, LB, WIDE, false, SHADOWS>(S, have, h, ro, rd, weight, (int)level, sink, wc);  // (barriers inside: every wavefront goes in)
     if (have) sink.store(i);
   }
@@ -209,14 +166,14 @@ hipError_t launch_primary_lb(int lb, dim3 grid, hipStream_t st, const DevScene& 
   return hipGetLastError();
 }
 
-template <bool WIDE, int SHADOWS>
-hipError_t launch_shade_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, uint32_t level, uint32_t n_roots,
+template <bool TRACK, int SHADOWS>
+hipError_t launch_level_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, uint32_t level, uint32_t n_roots,
                            const WavefrontBuffers& B) {
   switch (lb) {
-    case 1: hipLaunchKernelGGL((wf_shade_kernel<1, WIDE, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
-    case 2: hipLaunchKernelGGL((wf_shade_kernel<2, WIDE, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
-    case 4: hipLaunchKernelGGL((wf_shade_kernel<4, WIDE, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
-    default: hipLaunchKernelGGL((wf_shade_kernel<8, WIDE, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    case 1: hipLaunchKernelGGL((wf_level_kernel<1, true, TRACK, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    case 2: hipLaunchKernelGGL((wf_level_kernel<2, true, TRACK, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    case 4: hipLaunchKernelGGL((wf_level_kernel<4, true, TRACK, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    default: hipLaunchKernelGGL((wf_level_kernel<8, true, TRACK, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
   }
   return hipGetLastError();
 }
@@ -245,7 +202,7 @@ hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevC
   for (uint32_t tile_base = 0; tile_base < T.n_local_tiles; tile_base += pass_tiles) {
     const uint32_t n_tiles = std::min(pass_tiles, T.n_local_tiles - tile_base);
     const uint32_t n_roots = n_tiles * kBlock;
-    hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(64), 0, st, B.ctrl, B.cap_nodes, n_roots);
+    hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(64), 0, st, B.ctrl);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const dim3 grid(n_tiles);
     // the camera level: on the opaque path's bundle tests where they apply, else through trace_step
@@ -260,18 +217,17 @@ hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevC
     // One workgroup per tile of the pass: a level usually has fewer nodes than the pass has pixels, so most
     // workgroups take one run of 256 nodes (or none) and the hardware's dispatcher evens out what the nodes
     // cost; a level with more nodes than that gives every workgroup several runs.
-    const dim3 level_grid(std::min<uint32_t>(RTK_WF_GRID_MAX, n_tiles)), hit_grid(level_grid.x * (kBlock / RTK_WF_HIT_BLOCK));
+    const dim3 level_grid(std::min<uint32_t>(RTK_WF_GRID_MAX, n_tiles));
+    const int mode = shadow_mode(S);
     for (uint32_t level = 1; level < S.max_depth; ++level) {
       if (track)
-        hipLaunchKernelGGL((wf_hit_kernel<true, true>), hit_grid, dim3(RTK_WF_HIT_BLOCK), 0, st, S, level, n_roots, B);
+        e = mode == kShadowGrids   ? launch_level_lb<true, kShadowGrids>(lb, level_grid, st, S, level, n_roots, B)
+            : mode == kShadowWalks ? launch_level_lb<true, kShadowWalks>(lb, level_grid, st, S, level, n_roots, B)
+                                   : launch_level_lb<true, kShadowSweeps>(lb, level_grid, st, S, level, n_roots, B);
       else
-        hipLaunchKernelGGL((wf_hit_kernel<true, false>), hit_grid, dim3(RTK_WF_HIT_BLOCK), 0, st, S, level, n_roots, B);
-      if ((e = hipGetLastError()) != hipSuccess) return e;
-      switch (shadow_mode(S)) {
-        case kShadowGrids: e = launch_shade_lb<true, kShadowGrids>(lb, level_grid, st, S, level, n_roots, B); break;
-        case kShadowWalks: e = launch_shade_lb<true, kShadowWalks>(lb, level_grid, st, S, level, n_roots, B); break;
-        default: e = launch_shade_lb<true, kShadowSweeps>(lb, level_grid, st, S, level, n_roots, B); break;
-      }
+        e = mode == kShadowGrids   ? launch_level_lb<false, kShadowGrids>(lb, level_grid, st, S, level, n_roots, B)
+            : mode == kShadowWalks ? launch_level_lb<false, kShadowWalks>(lb, level_grid, st, S, level, n_roots, B)
+                                   : launch_level_lb<false, kShadowSweeps>(lb, level_grid, st, S, level, n_roots, B);
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(wf_gather_kernel, grid, dim3(kBlock), 0, st, S, C, T, tile_base, B.outs, B.cuts);

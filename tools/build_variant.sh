@@ -13,6 +13,6 @@ if [ -n "${ONLY:-}" ]; then rm -f $TMP/raytracer-rust_amd/csrc/$ONLY.o $TMP/rayt
 make -s -C $TMP/raytracer-rust_amd/csrc HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $*" librtk.so > /dev/null
 mkdir -p $ROOT/raytracer-rust_amd/csrc_ab/$NAME
 cp $TMP/raytracer-rust_amd/csrc/librtk.so $ROOT/raytracer-rust_amd/csrc_ab/$NAME/librtk.so
-cp $TMP/raytracer-rust_amd/csrc/opaque_resources.txt $ROOT/raytracer-rust_amd/csrc_ab/$NAME/ 2>/dev/null || true
+cp $TMP/raytracer-rust_amd/csrc/*_resources.txt $ROOT/raytracer-rust_amd/csrc_ab/$NAME/ 2>/dev/null || true
 rm -rf $TMP
 echo built $NAME

@@ -319,12 +319,12 @@ int rtk_untile_strided(rtk_context* ctx, uint32_t width, uint32_t height, uint32
  * (`Scene::trace` recurses, src/scene.rs:136-296); the frame is the same bit for bit either way.
  *   RTK_TRACE_DEPTH_FIRST: one lane walks a pixel's whole ray tree; needs no memory beyond the frame.
  *   RTK_TRACE_BY_LEVEL:    the nodes of all pixels are traced one tree level per launch from a queue in
- *                          device memory (124 bytes per node), the pixels are summed from the node
+ *                          device memory (104 bytes per node), the pixels are summed from the node
  *                          records afterwards in depth-first order.  No pixel holds a wavefront up, so
  *                          small and medium launches finish much sooner; large ones pay for the queue.
  *   RTK_TRACE_AUTO:        (default) by level where that is expected to be faster: scenes of more
  *                          than 8 objects, launches up to 64 million pixels (16 million below 256 spheres).
- * max_queue_nodes: capacity of the queue (0 keeps the current one; the default is 64 Mi nodes = 7.8 GB,
+ * max_queue_nodes: capacity of the queue (0 keeps the current one; the default is 64 Mi nodes = 6.5 GB,
  * or the environment variable RTK_WAVEFRONT_NODES read by rtk_create, where 0 turns tracing by level
  * off).  The queue is allocated on first use at 6 nodes per pixel of the launch, up to the capacity;
  * launches that need more run in passes, and a pass whose nodes still do not fit is traced again

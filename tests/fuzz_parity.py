@@ -5,7 +5,9 @@
                                                             glass, always w = 0 lights (FUZZ_LIGHTS=w1 / mixed /
                                                             exotic: those instead): the light grids and the
                                                             level-by-level order, at frame sizes either side of
-                                                            the library's choice between the two orders)
+                                                            the library's choice between the two orders;
+                                                            FUZZ_FIELDS=1: a random ambient colour and depth limit
+                                                            per scene as well)
 
 Scenes are drawn from wide ranges -- sphere radii over three decades, fields far from the origin,
 lights of every kind next to and far from the geometry, general affine transforms, every texture,
@@ -88,6 +90,12 @@ def main():
     for seed in range(seed0, seed0 + n_scenes):
         rng = np.random.default_rng(seed)
         scene, camera, what = random_scene(rtk, rng)
+        if os.environ.get("FUZZ_FIELDS"):  # the scene-wide fields too (a generator of their own: the scenes stay those of the seed)
+            r2 = np.random.default_rng(seed + 7_000_000)
+            if r2.random() < 0.7:
+                scene.ambient_color = rtk.rgb(*(r2.uniform(0.0, 0.3, 3) * (r2.random(3) < 0.8)))
+            scene.max_depth = int(r2.choice([1, 2, 3, 4, 5, 6, 8]))
+            what += f" ambient={tuple(round(float(v), 3) for v in scene.ambient_color)} depth={scene.max_depth}"
         canvas = dev.render(scene, camera)
         rgb, rgba, st = oracle.render(scene, camera, threads=16)
         d8 = np.abs(canvas.rgba8.astype(int) - rgba.astype(int)).max(axis=-1)

@@ -601,8 +601,11 @@ static bool build_trace_grid(const SphereKey* keys, uint32_t n_sph, const double
     return c;
   };
   double h = e_max / kAxisMax;
-  while (cells_at(h) > 2.0 * n_sph) h *= 1.1;
-  h = std::fmax(h, 0.75 * r_sum / n_sph);
+  double per_sphere = 2.0, least = 0.75;
+  if (const char* v = std::getenv("RTK_GRID_CELLS_PER_SPHERE")) per_sphere = std::fmax(0.05, std::atof(v));  // tuning knobs
+  if (const char* v = std::getenv("RTK_GRID_LEAST_CELL")) least = std::fmax(0.05, std::atof(v));
+  while (cells_at(h) > per_sphere * n_sph) h *= 1.1;
+  h = std::fmax(h, least * r_sum / n_sph);
   for (int attempt = 0; attempt < 5; ++attempt, h *= 1.6) {
     const double pad = 0.01 * h;  // the box begins a little outside the balls
     uint32_t n[3];

@@ -76,6 +76,16 @@ def random_scene(rtk, rng):
     return scene, camera, f"n={n} extent={extent:.3g} lights={kinds} glass={glass}"
 
 
+def vary_scene_fields(rtk, scene, seed):
+    """The scene-wide fields too: an ambient colour (some components zero) and a depth limit from 1 to 8.  A
+    generator of its own, so that the scene stays the one of the seed."""
+    r2 = np.random.default_rng(seed + 7_000_000)
+    if r2.random() < 0.7:
+        scene.ambient_color = rtk.rgb(*(r2.uniform(0.0, 0.3, 3) * (r2.random(3) < 0.8)))
+    scene.max_depth = int(r2.choice([1, 2, 3, 4, 5, 6, 8]))
+    return f" ambient={tuple(round(float(v), 3) for v in scene.ambient_color)} depth={scene.max_depth}"
+
+
 def main():
     n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -90,12 +100,8 @@ def main():
     for seed in range(seed0, seed0 + n_scenes):
         rng = np.random.default_rng(seed)
         scene, camera, what = random_scene(rtk, rng)
-        if os.environ.get("FUZZ_FIELDS"):  # the scene-wide fields too (a generator of their own: the scenes stay those of the seed)
-            r2 = np.random.default_rng(seed + 7_000_000)
-            if r2.random() < 0.7:
-                scene.ambient_color = rtk.rgb(*(r2.uniform(0.0, 0.3, 3) * (r2.random(3) < 0.8)))
-            scene.max_depth = int(r2.choice([1, 2, 3, 4, 5, 6, 8]))
-            what += f" ambient={tuple(round(float(v), 3) for v in scene.ambient_color)} depth={scene.max_depth}"
+        if os.environ.get("FUZZ_FIELDS"):
+            what += vary_scene_fields(rtk, scene, seed)
         canvas = dev.render(scene, camera)
         rgb, rgba, st = oracle.render(scene, camera, threads=16)
         d8 = np.abs(canvas.rgba8.astype(int) - rgba.astype(int)).max(axis=-1)

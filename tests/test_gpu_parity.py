@@ -772,6 +772,21 @@ def test_randomised_scenes(rtk, dev, oracle):
         check_against_oracle(dev, oracle, scene, camera, f"seed {seed}: {what}")
 
 
+def test_randomised_scenes_with_ambient_colour_and_depth_limits(rtk, dev, oracle):
+    """The same generator with a random ambient colour and a depth limit from 1 to 8 per scene, left to the
+    library's choice of order and forced level by level: children cut off by the depth limit add the ambient
+    colour times their weight, which the level-by-level order keeps in records of their own."""
+    from fuzz_parity import random_scene, vary_scene_fields
+
+    for order in (rtk.abi.RTK_TRACE_AUTO, rtk.abi.RTK_TRACE_BY_LEVEL):
+        dev.set_trace_order(order, 0)
+        for seed in range(5000, 5040):
+            scene, camera, what = random_scene(rtk, np.random.default_rng(seed))
+            what += vary_scene_fields(rtk, scene, seed)
+            check_against_oracle(dev, oracle, scene, camera, f"seed {seed}, order {order}: {what}")
+    dev.set_trace_order(rtk.abi.RTK_TRACE_AUTO, 0)
+
+
 # ---------------------------------------------------------------- more than one sample per pixel
 # The reference has one sample per pixel (src/scene/cameras.rs:53-54): the averaging step is
 # checked against the oracle's restatement of this library's own definition (parity unpinned);

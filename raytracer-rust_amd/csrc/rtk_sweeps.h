@@ -494,9 +494,13 @@ __device__ __forceinline__ void closest_general(const DevScene& S, bool active, 
 // along the walk) behind which nothing matters to the caller -- the best root so far of a closest-hit
 // search, the light's distance for a shadow ray; exact(sweep position) runs the caller's f64 test on a
 // sphere the filter kept and returns the t_stop that holds from then on (negative: the lane's walk ends).
+// Returns whether the lane's walk began in the cell of the ray's origin (the origin lies inside the grid's box).
+// origin_cell_done: a walk of the same ray the other way has been through that cell already -- the filter does
+// not depend on the direction's sign, so every sphere listed there that this walk would test has been tested
+// -- and a walk that begins there passes it by.
 template <typename ExactFn>
-__device__ __forceinline__ void grid_march(const DevScene& S, bool active, V3 o, V3 d, bool backward, double t_stop,
-                                           WaveCount& wc, ExactFn&& exact) {
+__device__ __forceinline__ bool grid_march(const DevScene& S, bool active, V3 o, V3 d, bool backward, double t_stop,
+                                           WaveCount& wc, ExactFn&& exact, bool origin_cell_done = false) {
   const double dd = dot3(d, d);
   double rs = __builtin_amdgcn_rsq(dd);
   rs = rs * __builtin_fma(-0.5 * dd, rs * rs, 1.5);  // one Newton step: a ray that enters the grid from 200,000 cells away must still enter it at the right place
@@ -578,7 +582,8 @@ __device__ __forceinline__ void grid_march(const DevScene& S, bool active, V3 o,
 #if defined(RTK_HIT_BUDGET)  // ... at most that many cells
   budget = RTK_HIT_BUDGET;
 #endif
-  if (alive) enter_cell();
+  const bool at_origin = alive && s_in == 0.0;
+  if (alive && !(origin_cell_done && at_origin)) enter_cell();  // (else: an empty list, and on to the cell's far side)
   [[maybe_unused]] int stat_rounds = 0;
   for (;;) {
     if (alive && kept == 0u) {
@@ -639,6 +644,7 @@ __device__ __forceinline__ void grid_march(const DevScene& S, bool active, V3 o,
       break;  // nobody waits, nobody works
     }
   }
+  return at_origin;
 }
 
 // May this lane's ray take the walk?  (Comparisons are written so that a NaN says no.)
@@ -677,6 +683,7 @@ __device__ __forceinline__ void closest_secondary(const DevScene& S, bool active
     }
   }
   // forward for the winner; then, where the winner's material asks for n1, backward for the entry before it
+  bool origin_cell_done = false;  // the forward walk began in the origin's cell and so tested what is listed there
 #pragma unroll 1
 #if defined(RTK_HIT_CUT) && RTK_HIT_CUT == 4  // experiment builds (wrong images): no walk against the direction
   for (int pass = 0; pass < 1; ++pass) {
@@ -703,7 +710,8 @@ __device__ __forceinline__ void closest_secondary(const DevScene& S, bool active
         }
         return backward ? -best.prev_t : best.t;
       };
-      grid_march(S, go, o, d, backward, backward ? -best.prev_t : best.t, wc, exact);
+      const bool began_there = grid_march(S, go, o, d, backward, backward ? -best.prev_t : best.t, wc, exact, backward && origin_cell_done);
+      if (!backward) origin_cell_done = go && began_there;
     }
   }
   const bool swept = active && !walks;

@@ -858,8 +858,11 @@ __global__ void __launch_bounds__(64, 5) render_uniform_kernel(DevScene S, DevCa
 #ifndef RTK_QP_OCC
 #define RTK_QP_OCC 5
 #endif
+#ifndef RTK_QP_TRACK_OCC
+#define RTK_QP_TRACK_OCC 5  // (a few spilled registers at five: 1-2 % faster than four from 4K on, the same at 1080p)
+#endif
 template <int KW, bool TRACK, bool TABULATED>
-__global__ void __launch_bounds__(kBlock, TRACK ? 4 : RTK_QP_OCC) queue_primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
+__global__ void __launch_bounds__(kBlock, TRACK ? RTK_QP_TRACK_OCC : RTK_QP_OCC) queue_primary_kernel(DevScene S, DevCamera C, const float4* __restrict__ prim,
                                                                  const float4* __restrict__ prim_ball,
                                                                  const float4* __restrict__ prim_cluster, RenderTarget T,
                                                                  uint32_t tile_base, WavefrontBuffers B) {

@@ -34,7 +34,7 @@ namespace rtk {
 #ifndef RTK_WF_GRID_MAX
 #define RTK_WF_GRID_MAX 65536u
 #endif
-// Start of a pass: no level has nodes yet.
+// Start of a pass after the first: no level has nodes yet.
 __global__ void wf_mark_kernel(unsigned int* ctrl) {
   if (blockIdx.x == 0 && threadIdx.x <= (unsigned)kMaxDepth) ctrl[kCtrlLevelCount + threadIdx.x] = 0u;
 }
@@ -202,8 +202,10 @@ hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevC
   for (uint32_t tile_base = 0; tile_base < T.n_local_tiles; tile_base += pass_tiles) {
     const uint32_t n_tiles = std::min(pass_tiles, T.n_local_tiles - tile_base);
     const uint32_t n_roots = n_tiles * kBlock;
-    hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(64), 0, st, B.ctrl);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (tile_base != 0u) {  // (the first pass finds the control block cleared)
+      hipLaunchKernelGGL(wf_mark_kernel, dim3(1), dim3(64), 0, st, B.ctrl);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     const dim3 grid(n_tiles);
     // the camera level: on the opaque path's bundle tests where they apply, else through trace_step
     if (queue_primary_bundled_applies(S, C))

@@ -904,7 +904,7 @@ __global__ void __launch_bounds__(kBlock, TRACK ? RTK_QP_TRACK_OCC : RTK_QP_OCC)
       }
     }
   }
-  QueueSink sink(S, B, gridDim.x * kBlock, gridDim.x * kBlock, 1u, s_counts);
+  QueueSink<4> sink(S, B, gridDim.x * kBlock, gridDim.x * kBlock, 1u, s_counts);
   V3 p = {0, 0, 0};
   if (hit) {
     const RTK_RO DevObject& ob = S.objects[obj];

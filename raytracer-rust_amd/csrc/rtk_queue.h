@@ -41,6 +41,7 @@ __device__ __forceinline__ double* ray_fields(const WavefrontBuffers& B, uint32_
 // children there straight from its registers, which are free again before the shadow rays start.
 // Children of neighbouring parents so stay neighbours in the queue whatever other workgroups push
 // meanwhile, and the next level's wavefronts (64 consecutive entries each) start close together.
+template <int WAVES>  // wavefronts of the workgroup (at most four)
 struct QueueSink {
   V3 t = {0, 0, 0};
   double w_refraction = 0.0, w_reflection = 0.0;
@@ -82,12 +83,14 @@ struct QueueSink {
     __syncthreads();
     if (threadIdx.x == 0) {
       uint32_t total = 0;
-      for (int i = 0; i < 8; ++i) total += s_counts[i];
+#pragma unroll
+      for (uint32_t w = 0; w < (uint32_t)WAVES; ++w) total += s_counts[w] + s_counts[4u + w];
       s_counts[8] = total ? atomicAdd(&B.ctrl[kCtrlLevelCount + child_depth], total) : 0u;
     }
     __syncthreads();
     uint32_t before0 = 0, before1 = 0;  // children of the workgroup queued ahead of this wavefront's, per kind
-    for (uint32_t w = 0; w < 4u; ++w) {
+#pragma unroll
+    for (uint32_t w = 0; w < (uint32_t)WAVES; ++w) {
       before1 += s_counts[w];
       if (w < wave) before0 += s_counts[w], before1 += s_counts[4u + w];
     }

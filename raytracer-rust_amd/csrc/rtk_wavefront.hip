@@ -34,6 +34,9 @@ namespace rtk {
 #ifndef RTK_WF_GRID_MAX
 #define RTK_WF_GRID_MAX 65536u
 #endif
+#ifndef RTK_WF_LEVEL_BLOCK
+#define RTK_WF_LEVEL_BLOCK 128  // threads of a workgroup of the level kernel, which takes one run of queue positions per batch of its nodes
+#endif
 // Start of a pass after the first: no level has nodes yet.
 __global__ void wf_mark_kernel(unsigned int* ctrl) {
   if (blockIdx.x == 0 && threadIdx.x <= (unsigned)kMaxDepth) ctrl[kCtrlLevelCount + threadIdx.x] = 0u;
@@ -56,7 +59,7 @@ __global__ void __launch_bounds__(kBlock, 4) wf_primary_kernel(DevScene S, DevCa
   const V3 dir = camera_ray_direction(C, x, y);
   WaveCount wc;
   __shared__ uint32_t s_counts[10];
-  QueueSink sink(S, B, gridDim.x * kBlock, gridDim.x * kBlock, 1u, s_counts);
+  QueueSink<4> sink(S, B, gridDim.x * kBlock, gridDim.x * kBlock, 1u, s_counts);
   trace_step<true, true, LB, WIDE, false, TRACK>(S, prim, prim_cluster, valid, true, origin, dir, 1.0, 0, sink, wc);
   sink.store(blockIdx.x * kBlock + threadIdx.x);
   flush_counts(counter_shard(B.counters), wc);
@@ -67,16 +70,19 @@ __global__ void __launch_bounds__(kBlock, 4) wf_primary_kernel(DevScene S, DevCa
 // stays in registers.  (Two launches, one finding the hits and one shading them with the hit handed over
 // through the queue, gave the first twice the wavefronts in flight at half the registers; the 116 bytes per
 // node that cost weigh more: one launch is 1-7 % faster on every scene measured but one, 0.6 % slower.)
-// Workgroups take 256 nodes at a time, dealt round-robin, and queue the children of the 256 together.
+// Workgroups of two wavefronts take 128 nodes at a time, dealt round-robin, and queue the children of the 128
+// together: a workgroup's resources fall free when its slowest wavefront is done, and its run of queue positions
+// costs one atomic on one address -- with four wavefronts (fewer atomics, longer waits for the slowest) a 1080p
+// glass frame takes 1.25 ms, with two 1.22, with one (as many atomics as wavefronts) 1.27.
 // (Handing nodes out through a counter in memory costs more than the uneven shares it avoids: one address
 // takes an atomic every 12 ns or so, and a level has tens of thousands of wavefronts' worth of nodes.)
 template <int LB, bool WIDE, bool TRACK, int SHADOWS>
-__global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_level_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
+__global__ void __launch_bounds__(RTK_WF_LEVEL_BLOCK, RTK_WF_OCC) wf_level_kernel(DevScene S, uint32_t level, uint32_t n_roots, WavefrontBuffers B) {
   const LevelBounds lv = level_bounds(B, n_roots, level);
   const uint32_t end = min(lv.end, B.cap_nodes);
   WaveCount wc;
   __shared__ uint32_t s_counts[10];
-  for (uint32_t base = lv.begin + blockIdx.x * kBlock; base < end; base += gridDim.x * kBlock) {
+  for (uint32_t base = lv.begin + blockIdx.x * RTK_WF_LEVEL_BLOCK; base < end; base += gridDim.x * RTK_WF_LEVEL_BLOCK) {
     const uint32_t i = base + threadIdx.x;
     const bool have = i < end;
     V3 ro = {0, 0, 0}, rd = {0, 0, 1};
@@ -88,7 +94,7 @@ __global__ void __launch_bounds__(kBlock, RTK_WF_OCC) wf_level_kernel(DevScene S
       weight = r[kRayWeight * 64];
     }
     const NodeHit h = find_hit<false, WIDE, false, TRACK>(S, nullptr, nullptr, have, false, ro, rd, (int)level, wc);
-    QueueSink sink(S, B, n_roots, lv.end, level + 1u, s_counts);
+    QueueSink<RTK_WF_LEVEL_BLOCK / 64> sink(S, B, n_roots, lv.end, level + 1u, s_counts);
     shade_hit<true, LB, WIDE, false, SHADOWS>(S, have, h, ro, rd, weight, (int)level, sink, wc);  // (barriers inside: every wavefront goes in)
     if (have) sink.store(i);
   }
@@ -170,10 +176,10 @@ template <bool TRACK, int SHADOWS>
 hipError_t launch_level_lb(int lb, dim3 grid, hipStream_t st, const DevScene& S, uint32_t level, uint32_t n_roots,
                            const WavefrontBuffers& B) {
   switch (lb) {
-    case 1: hipLaunchKernelGGL((wf_level_kernel<1, true, TRACK, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
-    case 2: hipLaunchKernelGGL((wf_level_kernel<2, true, TRACK, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
-    case 4: hipLaunchKernelGGL((wf_level_kernel<4, true, TRACK, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
-    default: hipLaunchKernelGGL((wf_level_kernel<8, true, TRACK, SHADOWS>), grid, dim3(kBlock), 0, st, S, level, n_roots, B); break;
+    case 1: hipLaunchKernelGGL((wf_level_kernel<1, true, TRACK, SHADOWS>), grid, dim3(RTK_WF_LEVEL_BLOCK), 0, st, S, level, n_roots, B); break;
+    case 2: hipLaunchKernelGGL((wf_level_kernel<2, true, TRACK, SHADOWS>), grid, dim3(RTK_WF_LEVEL_BLOCK), 0, st, S, level, n_roots, B); break;
+    case 4: hipLaunchKernelGGL((wf_level_kernel<4, true, TRACK, SHADOWS>), grid, dim3(RTK_WF_LEVEL_BLOCK), 0, st, S, level, n_roots, B); break;
+    default: hipLaunchKernelGGL((wf_level_kernel<8, true, TRACK, SHADOWS>), grid, dim3(RTK_WF_LEVEL_BLOCK), 0, st, S, level, n_roots, B); break;
   }
   return hipGetLastError();
 }
@@ -216,10 +222,10 @@ hipError_t launch_render_wavefront(hipStream_t st, const DevScene& S, const DevC
     if (e != hipSuccess) return e;
     // levels 1 .. max_depth - 1 (nodes at depth max_depth are not traced: their parents account for them);
     // enough resident workgroups to fill the GPU, no more than the pass could ever need
-    // One workgroup per tile of the pass: a level usually has fewer nodes than the pass has pixels, so most
-    // workgroups take one run of 256 nodes (or none) and the hardware's dispatcher evens out what the nodes
-    // cost; a level with more nodes than that gives every workgroup several runs.
-    const dim3 level_grid(std::min<uint32_t>(RTK_WF_GRID_MAX, n_tiles));
+    // As many threads as the pass has pixels: a level usually has fewer nodes than that, so most workgroups take
+    // one batch of nodes (or none) and the hardware's dispatcher evens out what the nodes cost; a level with
+    // more nodes gives every workgroup several batches.
+    const dim3 level_grid(std::min<uint32_t>(RTK_WF_GRID_MAX, n_tiles * (kBlock / RTK_WF_LEVEL_BLOCK)));
     const int mode = shadow_mode(S);
     for (uint32_t level = 1; level < S.max_depth; ++level) {
       if (track)
